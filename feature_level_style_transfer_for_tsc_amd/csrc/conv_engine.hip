@@ -1,0 +1,614 @@
+// Conv engine for gfx950: every convolution on the train-step hot path (omni-scale prime-kernel
+// layers, 1x1 shortcuts, WaveGlow dilated/1x1 convs, their data gradients and weight gradients) is
+// one of the two f32-MFMA kernels in this file, driven by a small "plan" table (plan.py).
+//
+//   conv_gemm_kernel   y[b,m,t]  = Σ_k A[m,k] · xcol[b,k,t]          (forward and data-gradient)
+//   conv_wgrad_kernel  dA[m,k]  += Σ_{b,t} dy[b,m,t] · xcol[b,k,t]   (weight gradient, split over b,t)
+//
+// Mapping to v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD — MI355X_MICROARCH "Matrix cores"):
+//   forward : A-operand = packed weights (lane ↔ output row, k ↔ channel parity), read from L2 as one
+//             coalesced 256-B record per k-step; B-operand = the input window staged ONCE in LDS as
+//             [channel][time], lane ↔ time so consecutive lanes hit consecutive banks; a tap is just
+//             an LDS column offset, so every kernel size of an omni-scale layer is produced from the
+//             same staged window.
+//   wgrad   : time is the MFMA k dimension; both operands come out of LDS transposed (odd row
+//             strides → conflict-free), accumulators are written with fp32 atomics whose lanes cover
+//             two 128-B segments (the full-rate shape, MI355X_MICROARCH "Global float atomics").
+#include "fst_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient
+// ------------------------------------------------------------------------------------------------
+struct ConvGemmParams {
+  const float* x[2];
+  long long x_bs[2];
+  const float* a;
+  const int32_t* plan;
+  const float* bias;
+  float* y;
+  long long y_bs;
+  const float* res;
+  long long res_bs;
+  float* y2;
+  long long y2_bs;
+  int msplit;
+  int B, L, M;
+  int tiles_per_seq, ksplit, flags, mg_per_wg, ldw;
+};
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TILE_N = 128 * NB;
+  const PlanView pv = plan_view(p.plan);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.tiles_per_seq;
+  const int t0 = (blockIdx.x - b * p.tiles_per_seq) * TILE_N;
+  const int g_begin = blockIdx.y * p.mg_per_wg;
+  const int g_end = min(pv.n_mgroups, g_begin + p.mg_per_wg);
+  const int q_begin = (int)(((long long)blockIdx.z * pv.n_chunks) / p.ksplit);
+  const int q_end = (int)(((long long)(blockIdx.z + 1) * pv.n_chunks) / p.ksplit);
+  const int wave_n0 = wave * NB * 32;
+  const int ldw = p.ldw, L = p.L, dil = pv.dil;
+
+  // staged window of chunk q, in units of LDS columns relative to (t0 - pad_left): [jlo, jlo+width)
+  auto window = [&](int q, int g0, int g1, int& jlo, int& width) {
+    int lo = 1 << 30, hi = -1;
+    for (int g = g0; g < g1; ++g) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      if (e[1] > e[0]) { lo = min(lo, e[0]); hi = max(hi, e[1]); }
+    }
+    if (hi < 0) { jlo = 0; width = 0; return; }
+    jlo = lo * dil;
+    width = (hi - 1 - lo) * dil + TILE_N;
+  };
+  auto stage = [&](int q, int jlo, int width) {
+    const int32_t* c = pv.chunk + 4 * q;
+    const int src = c[0], c_begin = c[1], c_count = c[2];
+    const int c_pad = (c_count + 1) & ~1;
+    const float* xb = p.x[src] + (long long)b * p.x_bs[src] + (long long)c_begin * L;
+    const int tbase = t0 - pv.pad_left + jlo;
+    for (int cc = wave; cc < c_pad; cc += 4) {
+      const float* row = xb + (long long)cc * L;
+      float* dst = lds + cc * ldw;
+      const bool live = cc < c_count;
+      for (int j = lane; j < width; j += 64) {
+        const int t = tbase + j;
+        dst[j] = (live && t >= 0 && t < L) ? row[t] : 0.f;
+      }
+    }
+  };
+
+  const bool stage_once = (q_end - q_begin == 1);
+  int jlo = 0, width = 0;
+  if (stage_once) {
+    window(q_begin, g_begin, g_end, jlo, width);
+    stage(q_begin, jlo, width);
+    __syncthreads();
+  }
+
+  for (int g = g_begin; g < g_end; ++g) {
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    for (int q = q_begin; q < q_end; ++q) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      const int lo = e[0], hi = e[1];
+      if (!stage_once) {
+        window(q, g, g + 1, jlo, width);
+        __syncthreads();   // previous chunk's readers are done
+        stage(q, jlo, width);
+        __syncthreads();
+      }
+      if (hi <= lo) continue;
+      const int c_pad = (pv.chunk[4 * q + 2] + 1) & ~1;
+      const float* ap = p.a + (long long)e[2] * (MB * 64) + lane;
+      for (int tap = lo; tap < hi; ++tap) {
+        const float* bp = lds + half * ldw + (tap * dil - jlo) + wave_n0 + l31;
+#pragma unroll 2
+        for (int cp = 0; cp < c_pad; cp += 2) {
+          float av[MB], bv[NB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) av[mb] = ap[mb * 64];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[nb * 32];
+          ap += MB * 64;
+          bp += 2 * ldw;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+        }
+      }
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA — col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool add_bias = p.bias != nullptr && blockIdx.z == 0;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (g * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= p.M) continue;
+        const float bias_v = add_bias ? p.bias[m] : 0.f;
+        float* dst;
+        const float* resp = nullptr;
+        bool accum;
+        if (m < p.msplit) {
+          dst = p.y + (long long)b * p.y_bs + (long long)m * L;
+          if (p.res) resp = p.res + (long long)b * p.res_bs + (long long)m * L;
+          accum = (p.flags & FST_EPI_ACC1) != 0;
+        } else {
+          dst = p.y2 + (long long)b * p.y2_bs + (long long)(m - p.msplit) * L;
+          accum = (p.flags & FST_EPI_ACC2) != 0;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int t = t0 + wave_n0 + nb * 32 + l31;
+          if (t >= L) continue;
+          float v = acc[mb][nb][r] + bias_v;
+          if (p.flags & FST_EPI_ATOMIC) {
+            atomicAdd(dst + t, v);
+          } else {
+            if (resp) v += resp[t];
+            if (accum) v += dst[t];
+            if (p.flags & FST_EPI_RELU) v = fmaxf(v, 0.f);
+            dst[t] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+typedef void (*conv_gemm_fn)(ConvGemmParams);
+
+static conv_gemm_fn pick_conv_gemm(int MB, int NB) {
+  if (NB == 1) {
+    switch (MB) {
+      case 1: return conv_gemm_kernel<1, 1>;
+      case 2: return conv_gemm_kernel<2, 1>;
+      case 4: return conv_gemm_kernel<4, 1>;
+      case 8: return conv_gemm_kernel<8, 1>;
+    }
+  } else if (NB == 2) {
+    switch (MB) {
+      case 1: return conv_gemm_kernel<1, 2>;
+      case 2: return conv_gemm_kernel<2, 2>;
+      case 4: return conv_gemm_kernel<4, 2>;
+    }
+  } else if (NB == 4) {
+    switch (MB) {
+      case 1: return conv_gemm_kernel<1, 4>;
+      case 2: return conv_gemm_kernel<2, 4>;
+    }
+  }
+  return nullptr;
+}
+
+int fst_check_plan(const int32_t* ph, int plan_len, int M, const char* who) {
+  FST_REQUIRE(ph != nullptr && plan_len >= FST_PLAN_HDR, "%s: plan missing or shorter than its header", who);
+  FST_REQUIRE(plan_expected_len(ph) == plan_len, "%s: plan length %d != expected %d", who, plan_len,
+              plan_expected_len(ph));
+  const PlanView pv = plan_view(ph);
+  FST_REQUIRE(pv.n_chunks > 0 && pv.n_mgroups > 0 && pv.ntaps > 0 && pv.dil > 0, "%s: bad plan header", who);
+  FST_REQUIRE(pv.MB == 1 || pv.MB == 2 || pv.MB == 4 || pv.MB == 8, "%s: MB=%d unsupported", who, pv.MB);
+  FST_REQUIRE(M > 0 && M <= pv.n_mgroups * pv.MB * 32, "%s: M=%d exceeds plan rows %d", who, M,
+              pv.n_mgroups * pv.MB * 32);
+  FST_REQUIRE((pv.chunk_cap & 1) == 0 && pv.chunk_cap > 0, "%s: chunk_cap must be even", who);
+  for (int q = 0; q < pv.n_chunks; ++q) {
+    const int32_t* c = pv.chunk + 4 * q;
+    FST_REQUIRE((c[0] == 0 || c[0] == 1) && c[1] >= 0 && c[2] > 0 && ((c[2] + 1) & ~1) <= pv.chunk_cap,
+                "%s: bad chunk %d", who, q);
+    for (int g = 0; g < pv.n_mgroups; ++g) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      FST_REQUIRE(e[0] >= 0 && e[1] <= pv.ntaps && e[2] >= 0, "%s: bad tap range at (g=%d,q=%d)", who, g, q);
+      const int nrec = e[1] > e[0] ? (e[1] - e[0]) * (((c[2] + 1) & ~1) / 2) : 0;
+      FST_REQUIRE(e[2] + nrec <= pv.total_records, "%s: record overflow at (g=%d,q=%d)", who, g, q);
+    }
+  }
+  return 0;
+}
+
+extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs, const float* a_packed,
+                             const int32_t* plan_dev, const int32_t* plan_host, int plan_len, const float* bias,
+                             float* y, int64_t y_bs, const float* res, int64_t res_bs, float* y2, int64_t y2_bs,
+                             int msplit, int B, int L, int M, int nb_cfg, int ksplit, int flags, void* stream) {
+  if (int rc = fst_check_plan(plan_host, plan_len, M, "fst_conv_gemm")) return rc;
+  const PlanView pv = plan_view(plan_host);
+  FST_REQUIRE(x0 && a_packed && plan_dev, "fst_conv_gemm: null operand");
+  FST_REQUIRE(B > 0 && L > 0, "fst_conv_gemm: B=%d L=%d", B, L);
+  FST_REQUIRE(msplit >= 0 && msplit <= M, "fst_conv_gemm: msplit=%d outside [0,%d]", msplit, M);
+  FST_REQUIRE(msplit == 0 || y != nullptr, "fst_conv_gemm: y is null but msplit=%d", msplit);
+  FST_REQUIRE(msplit == M || y2 != nullptr, "fst_conv_gemm: y2 is null but msplit=%d < M=%d", msplit, M);
+  FST_REQUIRE(ksplit >= 1 && ksplit <= pv.n_chunks, "fst_conv_gemm: ksplit=%d vs %d chunks", ksplit, pv.n_chunks);
+  FST_REQUIRE(ksplit == 1 || (flags & FST_EPI_ATOMIC), "fst_conv_gemm: ksplit>1 needs FST_EPI_ATOMIC");
+  bool needs_x1 = false;
+  for (int q = 0; q < pv.n_chunks; ++q) needs_x1 |= pv.chunk[4 * q] == 1;
+  FST_REQUIRE(!needs_x1 || x1 != nullptr, "fst_conv_gemm: plan reads input 1 but x1 is null");
+  conv_gemm_fn fn = pick_conv_gemm(pv.MB, nb_cfg);
+  FST_REQUIRE(fn != nullptr, "fst_conv_gemm: no kernel for MB=%d NB=%d", pv.MB, nb_cfg);
+  const int TILE_N = 128 * nb_cfg;
+
+  ConvGemmParams p;
+  p.x[0] = x0; p.x[1] = x1; p.x_bs[0] = x0_bs; p.x_bs[1] = x1_bs;
+  p.a = a_packed; p.plan = plan_dev; p.bias = bias;
+  p.y = y; p.y_bs = y_bs; p.res = res; p.res_bs = res_bs; p.y2 = y2; p.y2_bs = y2_bs; p.msplit = msplit;
+  p.B = B; p.L = L; p.M = M;
+  p.tiles_per_seq = (L + TILE_N - 1) / TILE_N;
+  p.ksplit = ksplit; p.flags = flags;
+  // one staged window feeds every M-group when the whole K range is a single chunk (omni-scale layers)
+  p.mg_per_wg = (pv.n_chunks == 1) ? pv.n_mgroups : 1;
+  int max_w = 0;
+  for (int q = 0; q < pv.n_chunks; ++q) {
+    if (p.mg_per_wg > 1) {
+      int lo = 1 << 30, hi = -1;
+      for (int g = 0; g < pv.n_mgroups; ++g) {
+        const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+        if (e[1] > e[0]) { lo = lo < e[0] ? lo : e[0]; hi = hi > e[1] ? hi : e[1]; }
+      }
+      if (hi >= 0) { int w = (hi - 1 - lo) * pv.dil + TILE_N; max_w = max_w > w ? max_w : w; }
+    } else {
+      for (int g = 0; g < pv.n_mgroups; ++g) {
+        const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+        if (e[1] > e[0]) { int w = (e[1] - 1 - e[0]) * pv.dil + TILE_N; max_w = max_w > w ? max_w : w; }
+      }
+    }
+  }
+  FST_REQUIRE(max_w > 0, "fst_conv_gemm: plan has no live taps");
+  p.ldw = max_w;
+  const size_t lds_bytes = (size_t)pv.chunk_cap * p.ldw * sizeof(float);
+  FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_conv_gemm: LDS window %zu B exceeds 160 KiB (chunk_cap=%d ldw=%d)",
+              lds_bytes, pv.chunk_cap, p.ldw);
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { fst_set_error("fst_conv_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  dim3 grid((unsigned)(B * p.tiles_per_seq), (unsigned)((pv.n_mgroups + p.mg_per_wg - 1) / p.mg_per_wg), (unsigned)ksplit);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds_bytes, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+  const float* x[2];
+  long long x_bs[2];
+  const float* dy;
+  long long dy_bs;
+  const float* dy2;
+  long long dy2_bs;
+  int msplit;
+  float* da;
+  const int32_t* plan;
+  int B, L, M, ksplit, tiles_per_seq, ldw, region_floats, n_regions;
+};
+
+#define WG_ITEMS 4   // row-blocks (32 packed K-rows each) per workgroup
+
+template <int CB, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int MBW = 4 * CB;
+  constexpr int DYS = TW + 1;   // odd row stride: lanes ↔ rows never share a bank
+  const PlanView pv = plan_view(p.plan);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int L = p.L, dil = pv.dil, ldw = p.ldw;
+
+  float* xreg = lds;                                     // n_regions windows of region_floats
+  float* zrow = lds + p.n_regions * p.region_floats;     // TW+2 zeros
+  float* dyt = zrow + (TW + 2 + 3) / 4 * 4;              // [MBW*32][DYS]
+
+  // decode this workgroup's items (all share one M-group)
+  int it_q[WG_ITEMS], it_rb[WG_ITEMS], it_region[WG_ITEMS];
+  int g = -1, nit = 0;
+#pragma unroll
+  for (int i = 0; i < WG_ITEMS; ++i) {
+    const int32_t* it = pv.item + 4 * (blockIdx.y * WG_ITEMS + i);
+    it_q[i] = it[1]; it_rb[i] = it[2];
+    if (it[1] >= 0) { g = it[0]; nit = i + 1; }
+    // consecutive items of one chunk share a staged window
+    it_region[i] = i == 0 ? 0 : (it_q[i] == it_q[i - 1] ? it_region[i - 1] : it_region[i - 1] + 1);
+  }
+  if (g < 0) return;
+  const int m0 = g * MBW * 32;
+
+  // per-lane LDS row offset of each item's A-operand row (a packed K-row = (tap, channel))
+  int rowoff[WG_ITEMS];
+#pragma unroll
+  for (int i = 0; i < WG_ITEMS; ++i) {
+    rowoff[i] = (int)(zrow - lds);
+    if (i < nit) {
+      const int q = it_q[i];
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      const int c_pad = (pv.chunk[4 * q + 2] + 1) & ~1;
+      const int nrows = (e[1] - e[0]) * c_pad;
+      const int r = it_rb[i] * 32 + l31;
+      if (r < nrows) {
+        const int tapi = r / c_pad, c = r - tapi * c_pad;
+        rowoff[i] = it_region[i] * p.region_floats + c * ldw + tapi * dil;
+      }
+    }
+  }
+  for (int j = tid; j < TW + 2; j += 256) zrow[j] = 0.f;
+
+  f32x16 acc[WG_ITEMS][CB];
+#pragma unroll
+  for (int i = 0; i < WG_ITEMS; ++i)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.f;
+
+  const int n_tiles = p.B * p.tiles_per_seq;
+  const int tile_begin = (int)(((long long)blockIdx.x * n_tiles) / p.ksplit);
+  const int tile_end = (int)(((long long)(blockIdx.x + 1) * n_tiles) / p.ksplit);
+
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    const int b = tile / p.tiles_per_seq;
+    const int tt0 = (tile - b * p.tiles_per_seq) * TW;
+    __syncthreads();   // previous tile's readers are done
+    // stage the X windows (one per distinct chunk among the items)
+#pragma unroll
+    for (int i = 0; i < WG_ITEMS; ++i) {
+      if (i >= nit || (i > 0 && it_region[i] == it_region[i - 1])) continue;
+      const int q = it_q[i];
+      const int32_t* c = pv.chunk + 4 * q;
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      const int src = c[0], c_count = c[2], c_pad = (c[2] + 1) & ~1;
+      const int width = (e[1] - 1 - e[0]) * dil + TW;
+      const int tbase = tt0 - pv.pad_left + e[0] * dil;
+      const float* xb = p.x[src] + (long long)b * p.x_bs[src] + (long long)c[1] * L;
+      float* reg = xreg + it_region[i] * p.region_floats;
+      for (int cc = wave; cc < c_pad; cc += 4) {
+        const float* row = xb + (long long)cc * L;
+        const bool live = cc < c_count;
+        for (int j = lane; j < width; j += 64) {
+          const int t = tbase + j;
+          reg[cc * ldw + j] = (live && t >= 0 && t < L) ? row[t] : 0.f;
+        }
+      }
+    }
+    // stage the dy tile [MBW*32][TW]
+    static_assert(TW == 32, "dy staging maps one half-wave to one 32-sample row");
+    for (int ml = wave * 2 + half; ml < MBW * 32; ml += 8) {
+      const int m = m0 + ml;
+      const float* row = nullptr;
+      if (m < p.M)
+        row = (m < p.msplit) ? p.dy + (long long)b * p.dy_bs + (long long)m * L
+                             : p.dy2 + (long long)b * p.dy2_bs + (long long)(m - p.msplit) * L;
+      const int t = tt0 + l31;
+      dyt[ml * DYS + l31] = (row != nullptr && t < L) ? row[t] : 0.f;
+    }
+    __syncthreads();
+
+    const float* bbase = dyt + (wave * CB * 32 + l31) * DYS + half;
+#pragma unroll 4
+    for (int tau = 0; tau < TW; tau += 2) {
+      float av[WG_ITEMS], bv[CB];
+#pragma unroll
+      for (int i = 0; i < WG_ITEMS; ++i) av[i] = lds[rowoff[i] + tau + half];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) bv[cb] = bbase[cb * 32 * DYS + tau];
+#pragma unroll
+      for (int i = 0; i < WG_ITEMS; ++i) {
+        if (i < nit) {
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb)
+            acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[cb], acc[i][cb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // epilogue: acc rows = packed K-rows (tap, channel), cols = output channel m (lane) → record layout
+#pragma unroll
+  for (int i = 0; i < WG_ITEMS; ++i) {
+    if (i >= nit) continue;
+    const int q = it_q[i];
+    const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+    const int c_pad = (pv.chunk[4 * q + 2] + 1) & ~1;
+    const int nrows = (e[1] - e[0]) * c_pad;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = it_rb[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row >= nrows) continue;
+      const int tapi = row / c_pad, c = row - tapi * c_pad;
+      const long long rec = (long long)e[2] + tapi * (c_pad / 2) + (c >> 1);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int mbw = wave * CB + cb;
+        float* dst = p.da + (rec * MBW + mbw) * 64 + (c & 1) * 32 + l31;
+        atomicAdd(dst, acc[i][cb][r]);
+      }
+    }
+  }
+}
+
+extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs, const float* dy,
+                              int64_t dy_bs, const float* dy2, int64_t dy2_bs, int msplit, float* da_packed,
+                              const int32_t* plan_dev, const int32_t* plan_host, int plan_len, int B, int L, int M,
+                              int ksplit, void* stream) {
+  if (int rc = fst_check_plan(plan_host, plan_len, M, "fst_conv_wgrad")) return rc;
+  const PlanView pv = plan_view(plan_host);
+  FST_REQUIRE(x0 && dy && da_packed && plan_dev, "fst_conv_wgrad: null operand");
+  FST_REQUIRE(pv.MB == 4 || pv.MB == 8, "fst_conv_wgrad: plan MB must be 4 or 8 (got %d)", pv.MB);
+  FST_REQUIRE(pv.n_items > 0 && pv.items_per_wg == WG_ITEMS && pv.n_items % WG_ITEMS == 0,
+              "fst_conv_wgrad: plan has no item table for %d items/workgroup", WG_ITEMS);
+  FST_REQUIRE(msplit >= 0 && msplit <= M && (msplit == M || dy2 != nullptr), "fst_conv_wgrad: bad msplit=%d", msplit);
+  FST_REQUIRE(B > 0 && L > 0 && ksplit >= 1, "fst_conv_wgrad: bad sizes");
+  bool needs_x1 = false;
+  for (int q = 0; q < pv.n_chunks; ++q) needs_x1 |= pv.chunk[4 * q] == 1;
+  FST_REQUIRE(!needs_x1 || x1 != nullptr, "fst_conv_wgrad: plan reads input 1 but x1 is null");
+  for (int i = 0; i < pv.n_items; ++i) {
+    const int32_t* it = pv.item + 4 * i;
+    FST_REQUIRE(it[1] < pv.n_chunks && (it[1] < 0 || (it[0] >= 0 && it[0] < pv.n_mgroups && it[2] >= 0)),
+                "fst_conv_wgrad: bad item %d", i);
+  }
+  constexpr int TW = 32;
+  WgradParams p;
+  p.x[0] = x0; p.x[1] = x1; p.x_bs[0] = x0_bs; p.x_bs[1] = x1_bs;
+  p.dy = dy; p.dy_bs = dy_bs; p.dy2 = dy2; p.dy2_bs = dy2_bs; p.msplit = msplit;
+  p.da = da_packed; p.plan = plan_dev; p.B = B; p.L = L; p.M = M;
+  p.tiles_per_seq = (L + TW - 1) / TW;
+  const int n_tiles = B * p.tiles_per_seq;
+  p.ksplit = ksplit < n_tiles ? ksplit : n_tiles;
+  int max_w = 0;
+  for (int q = 0; q < pv.n_chunks; ++q)
+    for (int g = 0; g < pv.n_mgroups; ++g) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      if (e[1] > e[0]) { int w = (e[1] - 1 - e[0]) * pv.dil + TW; max_w = max_w > w ? max_w : w; }
+    }
+  FST_REQUIRE(max_w > 0, "fst_conv_wgrad: plan has no live taps");
+  p.ldw = max_w | 1;                                     // odd stride: A-operand lanes walk channels
+  p.region_floats = (pv.chunk_cap * p.ldw + 3) / 4 * 4;
+  p.n_regions = 1;
+  for (int w = 0; w < pv.n_items / WG_ITEMS; ++w) {
+    int distinct = 0, prev = -2;
+    for (int i = 0; i < WG_ITEMS; ++i) {
+      const int q = pv.item[4 * (w * WG_ITEMS + i) + 1];
+      if (q >= 0 && q != prev) ++distinct;
+      prev = q;
+    }
+    p.n_regions = p.n_regions > distinct ? p.n_regions : distinct;
+  }
+  const size_t lds_floats = (size_t)p.n_regions * p.region_floats + (TW + 2 + 3) / 4 * 4 + (size_t)pv.MB * 32 * (TW + 1);
+  const size_t lds_bytes = lds_floats * sizeof(float);
+  FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_conv_wgrad: LDS %zu B exceeds 160 KiB", lds_bytes);
+  void (*fn)(WgradParams) = pv.MB == 8 ? conv_wgrad_kernel<2, TW> : conv_wgrad_kernel<1, TW>;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { fst_set_error("fst_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  dim3 grid((unsigned)p.ksplit, (unsigned)(pv.n_items / WG_ITEMS), 1);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds_bytes, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack / unpack between PyTorch weight layout and the plan's record layout
+// ------------------------------------------------------------------------------------------------
+struct PackParams {
+  const int32_t* plan;
+  fst_wsrc src[2];
+  float* dst[2];       // unpack targets
+  float* a;            // packed buffer (written by pack, read by unpack)
+  int M;
+  int unpack;
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(PackParams p) {
+  const PlanView pv = plan_view(p.plan);
+  const int gq = blockIdx.y;
+  const int g = gq / pv.n_chunks, q = gq - g * pv.n_chunks;
+  const int32_t* e = pv.mg + 4 * gq;
+  const int32_t* c = pv.chunk + 4 * q;
+  const int lo = e[0], hi = e[1];
+  if (hi <= lo) return;
+  const int MB = pv.MB, c_pad = (c[2] + 1) & ~1, half_c = c_pad / 2;
+  const long long elems = (long long)(hi - lo) * half_c * MB * 64;
+  const int s = c[0];
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < elems; idx += (long long)gridDim.x * 256) {
+    const int lane = (int)(idx & 63);
+    const long long rm = idx >> 6;
+    const int mb = (int)(rm % MB);
+    const int rec = (int)(rm / MB);
+    const int tapi = rec / half_c, cp = rec - tapi * half_c;
+    const int m = (g * MB + mb) * 32 + (lane & 31);
+    const int cl = 2 * cp + (lane >> 5);
+    const bool valid = m < p.M && cl < c[2];
+    const long long woff = p.src[s].off0 + (long long)m * p.src[s].sm + (long long)(c[1] + cl) * p.src[s].sc +
+                           (long long)(lo + tapi) * p.src[s].st;
+    float* ap = p.a + ((long long)e[2] + rec) * (MB * 64) + mb * 64 + lane;
+    if (p.unpack) {
+      if (valid) p.dst[s][woff] = *ap;
+    } else {
+      *ap = valid ? p.src[s].w[woff] : 0.f;
+    }
+  }
+}
+
+static int launch_pack(const int32_t* plan_dev, const int32_t* plan_host, int plan_len, const PackParams& p0,
+                       const char* who, void* stream) {
+  if (int rc = fst_check_plan(plan_host, plan_len, p0.M, who)) return rc;
+  const PlanView pv = plan_view(plan_host);
+  long long max_elems = 0;
+  for (int gq = 0; gq < pv.n_chunks * pv.n_mgroups; ++gq) {
+    const int32_t* e = pv.mg + 4 * gq;
+    const int32_t* c = pv.chunk + 4 * (gq % pv.n_chunks);
+    if (e[1] > e[0]) {
+      long long el = (long long)(e[1] - e[0]) * (((c[2] + 1) & ~1) / 2) * pv.MB * 64;
+      max_elems = max_elems > el ? max_elems : el;
+    }
+  }
+  FST_REQUIRE(max_elems > 0, "%s: plan has no live taps", who);
+  long long bx = (max_elems + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  PackParams p = p0;
+  p.plan = plan_dev;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)(pv.n_chunks * pv.n_mgroups)), dim3(256), 0,
+                     (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fst_pack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
+                                const fst_wsrc* src0, const fst_wsrc* src1, int M, float* a_packed, void* stream) {
+  FST_REQUIRE(plan_dev && src0 && src0->w && a_packed, "fst_pack_weights: null operand");
+  PackParams p = {};
+  p.src[0] = *src0;
+  if (src1) p.src[1] = *src1;
+  p.a = a_packed; p.M = M; p.unpack = 0;
+  const PlanView pv = plan_view(plan_host);
+  if (plan_len >= FST_PLAN_HDR)
+    for (int q = 0; q < pv.n_chunks; ++q)
+      FST_REQUIRE(pv.chunk[4 * q] == 0 || (src1 && src1->w), "fst_pack_weights: plan reads input 1 but src1 is null");
+  return launch_pack(plan_dev, plan_host, plan_len, p, "fst_pack_weights", stream);
+}
+
+extern "C" int fst_unpack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len, const float* a_packed,
+                                  int M, float* dw0, int64_t off0_0, int64_t sm0, int64_t sc0, int64_t st0, float* dw1,
+                                  int64_t off0_1, int64_t sm1, int64_t sc1, int64_t st1, void* stream) {
+  FST_REQUIRE(plan_dev && dw0 && a_packed, "fst_unpack_weights: null operand");
+  PackParams p = {};
+  p.src[0] = {nullptr, off0_0, sm0, sc0, st0};
+  p.src[1] = {nullptr, off0_1, sm1, sc1, st1};
+  p.dst[0] = dw0; p.dst[1] = dw1;
+  p.a = const_cast<float*>(a_packed); p.M = M; p.unpack = 1;
+  const PlanView pv = plan_view(plan_host);
+  if (plan_len >= FST_PLAN_HDR)
+    for (int q = 0; q < pv.n_chunks; ++q)
+      FST_REQUIRE(pv.chunk[4 * q] == 0 || dw1, "fst_unpack_weights: plan reads input 1 but dw1 is null");
+  return launch_pack(plan_dev, plan_host, plan_len, p, "fst_unpack_weights", stream);
+}
+
+// W ← W ⊙ mask for an omni-scale layer: taps outside [lo[m], hi[m]) of output channel m are zeroed.
+__global__ void mask_taps_kernel(float* w, const int32_t* lo, const int32_t* hi, int M, int C, int K) {
+  const long long n = (long long)M * C * K;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int m = (int)(i / ((long long)C * K));
+    if (k < lo[m] || k >= hi[m]) w[i] = 0.f;
+  }
+}
+
+extern "C" int fst_mask_taps(float* w, const int32_t* live_lo, const int32_t* live_hi, int M, int C, int K, void* stream) {
+  FST_REQUIRE(w && live_lo && live_hi && M > 0 && C > 0 && K > 0, "fst_mask_taps: bad arguments");
+  const long long n = (long long)M * C * K;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mask_taps_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, live_lo, live_hi, M, C, K);
+  FST_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,369 @@
+// HBM-bound pointwise / per-channel reduction kernels of the hot path (BatchNorm, gate, affine
+// coupling, bias-gradient row sums).  One pass per tensor, coalesced along time, wave64 shuffles for
+// the per-channel reductions, one atomic per block per channel.
+#include "fst_common.h"
+
+static thread_local char g_err[512] = "";
+void fst_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* fst_last_error(void) { return g_err; }
+extern "C" int fst_version(void) { return FST_ABI_VERSION; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum of two values; result valid in thread 0
+__device__ __forceinline__ void block_sum2(float& a, float& b) {
+  __shared__ float sa[4], sb[4];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sa[wave] = a; sb[wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = sa[0] + sa[1] + sa[2] + sa[3];
+    b = sb[0] + sb[1] + sb[2] + sb[3];
+  }
+  __syncthreads();
+}
+
+#define CH_SPLIT 16   // blocks per channel for the (B,L) reductions
+
+// ---------------------------------------------------------------- row sums (bias / beta gradients)
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* x, long long x_bs, int B, int C, int L, float* out) {
+  const int c = blockIdx.x;
+  float s = 0.f, dummy = 0.f;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const float* row = x + (long long)b * x_bs + (long long)c * L;
+    for (int t = threadIdx.x; t < L; t += 256) s += row[t];
+  }
+  block_sum2(s, dummy);
+  if (threadIdx.x == 0) atomicAdd(out + c, s);
+}
+
+extern "C" int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, void* stream) {
+  FST_REQUIRE(x && out && B > 0 && C > 0 && L > 0, "fst_row_sum: bad arguments");
+  hipLaunchKernelGGL(row_sum_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)x_bs, B, C, L, out);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- BatchNorm
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int B, int C, int L, float* sums) {
+  const int c = blockIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const float* row = y + ((long long)b * C + c) * L;
+    for (int t = threadIdx.x; t < L; t += 256) {
+      const float v = row[t];
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + c, s1);
+    atomicAdd(sums + C + c, s2);
+  }
+}
+
+extern "C" int fst_bn_stats(const float* y, int B, int C, int L, float* sums, void* stream) {
+  FST_REQUIRE(y && sums && B > 0 && C > 0 && L > 0, "fst_bn_stats: bad arguments");
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, y, B, C, L, sums);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void bn_finalize_kernel(const float* sums, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                   int train, int N, int C, float eps, float momentum, float* stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (train) {
+    const double m = (double)sums[c] / N;
+    double v = (double)sums[C + c] / N - m * m;
+    if (v < 0) v = 0;
+    mean = (float)m;
+    var = (float)v;
+    const float unbiased = N > 1 ? (float)(v * ((double)N / (N - 1))) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+  } else {
+    mean = rmean[c];
+    var = rvar[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float scale = gamma[c] * invstd;
+  stats[c] = mean;
+  stats[C + c] = invstd;
+  stats[2 * C + c] = scale;
+  stats[3 * C + c] = beta[c] - mean * scale;
+}
+
+extern "C" int fst_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int train, int B, int C, int L, float eps, float momentum,
+                               float* stats, void* stream) {
+  FST_REQUIRE(gamma && beta && running_mean && running_var && stats && C > 0, "fst_bn_finalize: bad arguments");
+  FST_REQUIRE(!train || sums, "fst_bn_finalize: train mode needs sums");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta,
+                     running_mean, running_var, train, B * L, C, eps, momentum, stats);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, const float* stats, const float* res,
+                                                       const float* res_stats, float* out, int C, int L, int relu) {
+  const int bc = blockIdx.x;           // b*C + c
+  const int c = bc % C;
+  const float sc = stats[2 * C + c], sh = stats[3 * C + c];
+  float rsc = 1.f, rsh = 0.f;
+  if (res && res_stats) { rsc = res_stats[2 * C + c]; rsh = res_stats[3 * C + c]; }
+  const long long base = (long long)bc * L;
+  for (int t = threadIdx.x; t < L; t += 256) {
+    float v = y[base + t] * sc + sh;
+    if (res) v += res[base + t] * rsc + rsh;
+    if (relu) v = fmaxf(v, 0.f);
+    out[base + t] = v;
+  }
+}
+
+extern "C" int fst_bn_apply(const float* y, const float* stats, const float* res, const float* res_stats, float* out,
+                            int B, int C, int L, int relu, void* stream) {
+  FST_REQUIRE(y && stats && out && B > 0 && C > 0 && L > 0, "fst_bn_apply: bad arguments");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, y, stats, res, res_stats, out, C, L, relu);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, const float* y, const float* out,
+                                                            const float* stats, int B, int C, int L, int relu, float* red) {
+  const int c = blockIdx.x;
+  const float mean = stats[c], invstd = stats[C + c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const long long base = ((long long)b * C + c) * L;
+    for (int t = threadIdx.x; t < L; t += 256) {
+      float g = dy[base + t];
+      if (relu && !(out[base + t] > 0.f)) g = 0.f;
+      s1 += g;
+      s2 += g * (y[base + t] - mean) * invstd;
+    }
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    atomicAdd(red + c, s1);
+    atomicAdd(red + C + c, s2);
+  }
+}
+
+extern "C" int fst_bn_bwd_reduce(const float* dy, const float* y, const float* out, const float* stats, int B, int C,
+                                 int L, int relu, float* red, void* stream) {
+  FST_REQUIRE(dy && y && stats && red && (!relu || out), "fst_bn_bwd_reduce: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, dy, y,
+                     out, stats, B, C, L, relu, red);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* y, const float* out,
+                                                           const float* stats, const float* red, float* dx, int C, int L,
+                                                           int relu, int train, float invN) {
+  const int bc = blockIdx.x;
+  const int c = bc % C;
+  const float mean = stats[c], invstd = stats[C + c], scale = stats[2 * C + c];
+  const float m1 = train ? red[c] * invN : 0.f, m2 = train ? red[C + c] * invN : 0.f;
+  const long long base = (long long)bc * L;
+  for (int t = threadIdx.x; t < L; t += 256) {
+    float g = dy[base + t];
+    if (relu && !(out[base + t] > 0.f)) g = 0.f;
+    const float xh = (y[base + t] - mean) * invstd;
+    dx[base + t] = scale * (g - m1 - xh * m2);
+  }
+}
+
+extern "C" int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
+                                float* dx, int B, int C, int L, int relu, int train, void* stream) {
+  FST_REQUIRE(dy && y && stats && dx && (!relu || out) && (!train || red), "fst_bn_bwd_apply: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, y, out, stats, red, dx, C, L,
+                     relu, train, 1.0f / ((float)B * (float)L));
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- WaveGlow gate
+__global__ __launch_bounds__(256) void gate_fwd_kernel(float* g, float* acts, int n, int L) {
+  const int b = blockIdx.y;
+  const long long total = (long long)n * L;
+  float* gt = g + (long long)b * 2 * total;
+  float* gs = gt + total;
+  float* ab = acts + (long long)b * total;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float t = tanhf(gt[i]);
+    const float s = 1.0f / (1.0f + expf(-gs[i]));
+    gt[i] = t;
+    gs[i] = s;
+    ab[i] = t * s;
+  }
+}
+
+extern "C" int fst_gate_fwd(float* g_ts, float* acts, int B, int n, int L, void* stream) {
+  FST_REQUIRE(g_ts && acts && B > 0 && n > 0 && L > 0, "fst_gate_fwd: bad arguments");
+  long long blocks = ((long long)n * L + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, g_ts, acts, n, L);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* ts, const float* dacts, float* dg, int n, int L) {
+  const int b = blockIdx.y;
+  const long long total = (long long)n * L;
+  const float* tt = ts + (long long)b * 2 * total;
+  const float* ss = tt + total;
+  const float* da = dacts + (long long)b * total;
+  float* dgt = dg + (long long)b * 2 * total;
+  float* dgs = dgt + total;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float t = tt[i], s = ss[i], d = da[i];
+    dgt[i] = d * s * (1.f - t * t);
+    dgs[i] = d * t * s * (1.f - s);
+  }
+}
+
+extern "C" int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, int L, void* stream) {
+  FST_REQUIRE(ts && dacts && dg && B > 0 && n > 0 && L > 0, "fst_gate_bwd: bad arguments");
+  long long blocks = ((long long)n * L + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, ts, dacts, dg, n, L);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- affine coupling
+// mode 0: forward   xn1 = exp(s)*u1 + b          mode 1: inverse   xn1 = (x1 - b) / exp(s)
+__global__ __launch_bounds__(256) void coupling_fwd_kernel(const float* u, const float* o, float* xn, int h, int L, int mode) {
+  const int b = blockIdx.y;
+  const long long half = (long long)h * L;
+  const float* ub = u + (long long)b * 2 * half;
+  const float* ob = o + (long long)b * 2 * half;
+  float* xb = xn + (long long)b * 2 * half;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < half; i += (long long)gridDim.x * 256) {
+    xb[i] = ub[i];
+    const float bb = ob[i], s = ob[half + i], u1 = ub[half + i];
+    xb[half + i] = mode == 0 ? expf(s) * u1 + bb : (u1 - bb) / expf(s);
+  }
+}
+
+static int launch_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int mode, void* stream) {
+  FST_REQUIRE(u && o && xn && B > 0 && h > 0 && L > 0, "fst_coupling: bad arguments");
+  long long blocks = ((long long)h * L + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(coupling_fwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, xn, h, L, mode);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, void* stream) {
+  return launch_coupling_fwd(u, o, xn, B, h, L, 0, stream);
+}
+extern "C" int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, void* stream) {
+  return launch_coupling_fwd(x, o, xn, B, h, L, 1, stream);
+}
+
+// forward-coupling backward.  dxn: grad of xn (2h ch); dlogs: extra grad flowing into log_s (may be null)
+//   du0 = dxn0 ; du1 = dxn1*exp(s) ; db = dxn1 ; ds = dxn1*u1*exp(s) + dlogs
+__global__ __launch_bounds__(256) void coupling_bwd_kernel(const float* u, const float* o, const float* dxn,
+                                                           const float* dlogs, float* du, float* d_o, int h, int L) {
+  const int b = blockIdx.y;
+  const long long half = (long long)h * L;
+  const long long off = (long long)b * 2 * half;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < half; i += (long long)gridDim.x * 256) {
+    const float es = expf(o[off + half + i]);
+    const float g1 = dxn[off + half + i];
+    du[off + i] = dxn[off + i];
+    du[off + half + i] = g1 * es;
+    d_o[off + i] = g1;
+    float ds = g1 * u[off + half + i] * es;
+    if (dlogs) ds += dlogs[(long long)b * half + i];
+    d_o[off + half + i] = ds;
+  }
+}
+
+extern "C" int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, float* du,
+                                float* d_o, int B, int h, int L, void* stream) {
+  FST_REQUIRE(u && o && dxn && du && d_o && B > 0 && h > 0 && L > 0, "fst_coupling_bwd: bad arguments");
+  long long blocks = ((long long)h * L + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, dxn, dlogs, du, d_o, h, L);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// inverse-coupling backward: xn1 = (x1 - b)*exp(-s)
+//   dx0 = dxn0 ; dx1 = dxn1*exp(-s) ; db = -dxn1*exp(-s) ; ds = -dxn1*xn1
+__global__ __launch_bounds__(256) void coupling_inv_bwd_kernel(const float* xn, const float* o, const float* dxn,
+                                                               float* dx, float* d_o, int h, int L) {
+  const int b = blockIdx.y;
+  const long long half = (long long)h * L;
+  const long long off = (long long)b * 2 * half;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < half; i += (long long)gridDim.x * 256) {
+    const float ies = 1.0f / expf(o[off + half + i]);
+    const float g1 = dxn[off + half + i];
+    dx[off + i] = dxn[off + i];
+    dx[off + half + i] = g1 * ies;
+    d_o[off + i] = -g1 * ies;
+    d_o[off + half + i] = -g1 * xn[off + half + i];
+  }
+}
+
+extern "C" int fst_coupling_inv_bwd(const float* xn, const float* o, const float* dxn, float* dx, float* d_o, int B,
+                                    int h, int L, void* stream) {
+  FST_REQUIRE(xn && o && dxn && dx && d_o && B > 0 && h > 0 && L > 0, "fst_coupling_inv_bwd: bad arguments");
+  long long blocks = ((long long)h * L + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(coupling_inv_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, xn, o, dxn, dx, d_o, h, L);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- small helpers
+__global__ void axpy_kernel(float* y, const float* x, float alpha, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] += alpha * x[i];
+}
+extern "C" int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream) {
+  FST_REQUIRE(y && x && n > 0, "fst_axpy: bad arguments");
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, x, alpha, (long long)n);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void add_slices_kernel(float* dst, long long dst_bs, const float* a, long long a_bs,
+                                                         const float* bsrc, long long b_bs, int C, int L) {
+  const int b = blockIdx.y;
+  const long long total = (long long)C * L;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    float v = a[(long long)b * a_bs + i];
+    if (bsrc) v += bsrc[(long long)b * b_bs + i];
+    dst[(long long)b * dst_bs + i] = v;
+  }
+}
+extern "C" int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,
+                              int B, int C, int L, void* stream) {
+  FST_REQUIRE(dst && a && B > 0 && C > 0 && L > 0, "fst_add_slices: bad arguments");
+  long long blocks = ((long long)C * L + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(add_slices_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, dst, (long long)dst_bs, a,
+                     (long long)a_bs, b, (long long)b_bs, C, L);
+  FST_LAUNCH_CHECK();
+  return 0;
+}

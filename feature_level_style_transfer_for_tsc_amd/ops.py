@@ -1,0 +1,642 @@
+"""Autograd-visible ops of the hot path, each a thin host wrapper over the C ABI (include/fst_hip.h).
+
+Everything here launches hand-written gfx950 kernels on torch's current HIP stream; torch supplies
+device memory and the autograd graph only.  No op has a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import WSrc, check, ptr, stream_ptr
+from .plan import Plan, Segment, build_plan, pick_mb
+
+EPI_RELU, EPI_ACC2, EPI_ATOMIC, EPI_ACC1 = 1, 2, 4, 8
+LDS_BUDGET = 96 * 1024
+
+_PARTIAL_BACKWARD = False
+
+
+class partial_backward:
+    """Context: a backward pass whose only wanted parameter gradients belong to convs flagged
+    ``spec.always_weight_grad`` (GradNorm's shared OS_block); every other conv skips its weight-gradient kernels."""
+
+    def __enter__(self):
+        global _PARTIAL_BACKWARD
+        self._prev, _PARTIAL_BACKWARD = _PARTIAL_BACKWARD, True
+        return self
+
+    def __exit__(self, *exc):
+        global _PARTIAL_BACKWARD
+        _PARTIAL_BACKWARD = self._prev
+        return False
+
+
+def _want_weight_grad(spec=None) -> bool:
+    return (not _PARTIAL_BACKWARD) or bool(getattr(spec, "always_weight_grad", False))
+
+Tensor = torch.Tensor
+
+
+def _ncl(t: Tensor, name: str) -> Tuple[int, int]:
+    """Check an activation view is [B, C, L] with unit time stride and channel stride L; return (bs, L)."""
+    _lib.require_gpu_tensor(t, name)
+    if t.dim() != 3 or t.stride(2) != 1 or (t.size(1) > 1 and t.stride(1) != t.size(2)):
+        raise ValueError(f"{name}: expected NCL view with channel stride L, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0), t.size(2)
+
+
+def _wsrc(t: Optional[Tensor], off0: int, sm: int, sc: int, st: int) -> WSrc:
+    return WSrc(ptr(t) if t is not None else None, off0, sm, sc, st)
+
+
+# --------------------------------------------------------------------------------------------------
+# raw launches
+# --------------------------------------------------------------------------------------------------
+def pack_weights(plan: Plan, M: int, w0: Tensor, s0: Tuple[int, int, int, int], w1: Optional[Tensor] = None,
+                 s1: Tuple[int, int, int, int] = (0, 0, 0, 0)) -> Tensor:
+    lib = _lib.load()
+    a = torch.empty(plan.packed_floats, device=w0.device, dtype=torch.float32)
+    src0 = _wsrc(w0, *s0)
+    src1 = _wsrc(w1, *s1) if w1 is not None else None
+    check(lib.fst_pack_weights(ptr(plan.dev(w0.device)), plan.host_ptr(), plan.length, ctypes.byref(src0),
+                               ctypes.byref(src1) if src1 is not None else None, M, ptr(a), stream_ptr()),
+          "fst_pack_weights")
+    return a
+
+
+def unpack_weights(plan: Plan, M: int, a: Tensor, dw0: Tensor, s0, dw1: Optional[Tensor] = None, s1=(0, 0, 0, 0)) -> None:
+    lib = _lib.load()
+    check(lib.fst_unpack_weights(ptr(plan.dev(a.device)), plan.host_ptr(), plan.length, ptr(a), M, ptr(dw0), *s0,
+                                 ptr(dw1), *s1, stream_ptr()), "fst_unpack_weights")
+
+
+def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Optional[Tensor], B: int, L: int, M: int,
+              y: Optional[Tensor], res: Optional[Tensor] = None, y2: Optional[Tensor] = None, msplit: Optional[int] = None,
+              nb: int = 1, ksplit: int = 1, flags: int = 0) -> None:
+    lib = _lib.load()
+    msplit = M if msplit is None else msplit
+    x0_bs, _ = _ncl(x0, "x0")
+    x1_bs = _ncl(x1, "x1")[0] if x1 is not None else 0
+    y_bs = _ncl(y, "y")[0] if y is not None else 0
+    res_bs = _ncl(res, "res")[0] if res is not None else 0
+    y2_bs = _ncl(y2, "y2")[0] if y2 is not None else 0
+    check(lib.fst_conv_gemm(ptr(x0), x0_bs, ptr(x1), x1_bs, ptr(a), ptr(plan.dev(x0.device)), plan.host_ptr(),
+                            plan.length, ptr(bias), ptr(y), y_bs, ptr(res), res_bs, ptr(y2), y2_bs, msplit, B, L, M,
+                            nb, ksplit, flags, stream_ptr()), "fst_conv_gemm")
+
+
+def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor], msplit: int, B: int,
+               L: int, M: int, ksplit: int) -> Tensor:
+    lib = _lib.load()
+    da = torch.zeros(plan.packed_floats, device=x0.device, dtype=torch.float32)
+    x0_bs, _ = _ncl(x0, "x0")
+    x1_bs = _ncl(x1, "x1")[0] if x1 is not None else 0
+    dy_bs, _ = _ncl(dy, "dy")
+    dy2_bs = _ncl(dy2, "dy2")[0] if dy2 is not None else 0
+    check(lib.fst_conv_wgrad(ptr(x0), x0_bs, ptr(x1), x1_bs, ptr(dy), dy_bs, ptr(dy2), dy2_bs, msplit, ptr(da),
+                             ptr(plan.dev(x0.device)), plan.host_ptr(), plan.length, B, L, M, ksplit, stream_ptr()),
+          "fst_conv_wgrad")
+    return da
+
+
+def row_sum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    bs, L = _ncl(x, "x")
+    B, C = x.size(0), x.size(1)
+    if out is None:
+        out = torch.zeros(C, device=x.device, dtype=torch.float32)
+    check(lib.fst_row_sum(ptr(x), bs, B, C, L, ptr(out), stream_ptr()), "fst_row_sum")
+    return out
+
+
+def wgrad_ksplit(B: int, L: int, n_wg_per_slice: int) -> int:
+    """Split (b, t) so that the launch has ≈ 4 workgroups per CU."""
+    tiles = B * ((L + 31) // 32)
+    want = max(1, (1024 + n_wg_per_slice - 1) // n_wg_per_slice)
+    return max(1, min(tiles, want))
+
+
+# --------------------------------------------------------------------------------------------------
+# ConvSpec: one convolution's shape + its forward / data-gradient / weight-gradient plans
+# --------------------------------------------------------------------------------------------------
+class ConvSpec:
+    """y[b,m,t] = bias[m] + Σ_{c,k} w0[m,c,k]·x0[b,c,t+k·dil−pad_left] (+ Σ_c w1[m,c]·x1[b,c,t])."""
+
+    def __init__(self, M: int, C0: int, ntaps: int = 1, dil: int = 1, pad_left: int = 0, C1: int = 0,
+                 row_live: Optional[Sequence[Tuple[int, int]]] = None, dense_dw: bool = True):
+        self.M, self.C0, self.ntaps, self.dil, self.pad_left, self.C1 = M, C0, ntaps, dil, pad_left, C1
+        self.row_live = list(row_live) if row_live is not None else None
+        self.dense_dw = dense_dw
+        if C1:
+            if pad_left % dil or not (0 <= pad_left // dil < ntaps):
+                raise ValueError("the 1x1 side input needs a tap with zero offset")
+        self.x1_tap = pad_left // dil if C1 else 0
+        self._plans: Dict[Tuple[str, int], Plan] = {}
+        self.mb = 1 if self.row_live is not None and ntaps > 2 else pick_mb(M)
+
+    # ---- heuristics
+    def _halo(self) -> int:
+        return (self.ntaps - 1) * self.dil
+
+    def nb_for(self, B: int, L: int, mb: int, windowed_c: int, halo: int) -> int:
+        tiles128 = (L + 127) // 128
+        best = 1
+        for nb in (4, 2, 1):
+            if mb * nb > 8 or nb > max(1, tiles128):
+                continue
+            if windowed_c and ((windowed_c + 1) & ~1) * (128 * nb + halo) * 4 > LDS_BUDGET:
+                continue
+            best = nb
+            if B * ((L + 128 * nb - 1) // (128 * nb)) >= 512:
+                break
+        return best
+
+    def _fwd_segments(self) -> List[Segment]:
+        segs = [Segment(0, self.C0, 0, self.ntaps)]
+        if self.C1:
+            segs.append(Segment(1, self.C1, self.x1_tap, self.x1_tap + 1))
+        return segs
+
+    def _chunking(self, channels: int, nb: int, ntaps: int) -> Tuple[int, bool]:
+        """(chunk_c, split_taps): dilated taps are split so no chunk drags a halo; dense taps share a window."""
+        if self.dil > 1 and ntaps > 1:
+            return 32, True
+        halo = (ntaps - 1) * self.dil
+        cap = (LDS_BUDGET // (4 * (128 * nb + halo))) & ~1
+        if ntaps == 1:
+            cap = min(cap, 64)
+        if channels <= cap:
+            return (channels + 1) & ~1, False
+        n = (channels + cap - 1) // cap
+        return ((channels + n - 1) // n + 1) & ~1, False
+
+    # ---- plans
+    def fwd_plan(self, nb: int) -> Plan:
+        key = ("fwd", nb)
+        if key not in self._plans:
+            chunk_c, split = self._chunking(max(self.C0, self.C1), nb, self.ntaps)
+            self._plans[key] = build_plan(self.M, self._fwd_segments(), self.ntaps, self.dil, self.pad_left, MB=self.mb,
+                                          chunk_c=chunk_c, split_taps=split, row_live=self.row_live)
+        return self._plans[key]
+
+    def dx0_plan(self, nb: int) -> Plan:
+        key = ("dx0", nb)
+        if key not in self._plans:
+            col_live = None
+            if self.row_live is not None:
+                col_live = [(self.ntaps - hi, self.ntaps - lo) for lo, hi in self.row_live]
+            chunk_c, split = self._chunking(self.M, nb, self.ntaps)
+            self._plans[key] = build_plan(self.C0, [Segment(0, self.M, 0, self.ntaps, col_live)], self.ntaps, self.dil,
+                                          self._halo() - self.pad_left, chunk_c=chunk_c, split_taps=split)
+        return self._plans[key]
+
+    def dx1_plan(self, nb: int) -> Plan:
+        key = ("dx1", nb)
+        if key not in self._plans:
+            self._plans[key] = build_plan(self.C1, [Segment(0, self.M, 0, 1)], 1, 1, 0, chunk_c=64)
+        return self._plans[key]
+
+    def wg_plan(self) -> Plan:
+        key = ("wg", 0)
+        if key not in self._plans:
+            split = self.dil > 1 and self.ntaps > 1
+            cmax = max(self.C0, self.C1)
+            chunk_c = 32 if (split or self.ntaps == 1) else (cmax + 1) & ~1
+            self._plans[key] = build_plan(self.M, self._fwd_segments(), self.ntaps, self.dil, self.pad_left,
+                                          MB=4 if self.M <= 128 else 8, chunk_c=min(chunk_c, 64), split_taps=split,
+                                          row_live=None if self.dense_dw else self.row_live, with_items=True)
+        return self._plans[key]
+
+    # ---- weight views
+    def s_w0(self):
+        return (0, self.C0 * self.ntaps, self.ntaps, 1)
+
+    def s_w1(self):
+        return (0, self.C1, 1, 0)
+
+    def s_w0_T(self):
+        """rows = input channel, K-channel = output row, taps flipped"""
+        return (self.ntaps - 1, self.ntaps, self.C0 * self.ntaps, -1)
+
+    def s_w1_T(self):
+        return (0, 1, self.C1, 0)
+
+    # ---- launches
+    def forward(self, x0: Tensor, x1: Optional[Tensor], w0: Tensor, w1: Optional[Tensor], bias: Optional[Tensor],
+                y: Optional[Tensor] = None, res: Optional[Tensor] = None, y2: Optional[Tensor] = None,
+                msplit: Optional[int] = None, flags: int = 0) -> Tensor:
+        B, L = x0.size(0), x0.size(2)
+        windowed = self.C0 if (self.dil == 1 and self.ntaps > 1 and self.C0 <= 64) else 0
+        nb = self.nb_for(B, L, self.mb, windowed, self._halo())
+        plan = self.fwd_plan(nb)
+        a = pack_weights(plan, self.M, w0, self.s_w0(), w1, self.s_w1())
+        if y is None and (msplit is None or msplit > 0):
+            y = torch.empty(B, self.M if msplit is None else msplit, L, device=x0.device, dtype=torch.float32)
+        conv_gemm(plan, a, x0, x1, bias, B, L, self.M, y, res, y2, msplit, nb=nb, flags=flags)
+        return y
+
+    def grad_x0(self, dy: Tensor, w0: Tensor, out: Optional[Tensor] = None, res: Optional[Tensor] = None,
+                flags: int = 0) -> Tensor:
+        B, L = dy.size(0), dy.size(2)
+        mb = pick_mb(self.C0)
+        windowed = self.M if (self.dil == 1 and self.ntaps > 1 and self.M <= 64) else 0
+        nb = self.nb_for(B, L, mb, windowed, self._halo())
+        plan = self.dx0_plan(nb)
+        a = pack_weights(plan, self.C0, w0, self.s_w0_T())
+        if out is None:
+            out = torch.empty(B, self.C0, L, device=dy.device, dtype=torch.float32)
+        conv_gemm(plan, a, dy, None, None, B, L, self.C0, out, res, nb=nb, flags=flags)
+        return out
+
+    def grad_x1(self, dy: Tensor, w1: Tensor, out: Optional[Tensor] = None, flags: int = 0) -> Tensor:
+        B, L = dy.size(0), dy.size(2)
+        nb = self.nb_for(B, L, pick_mb(self.C1), 0, 0)
+        plan = self.dx1_plan(nb)
+        a = pack_weights(plan, self.C1, w1, self.s_w1_T())
+        if out is None:
+            out = torch.empty(B, self.C1, L, device=dy.device, dtype=torch.float32)
+        conv_gemm(plan, a, dy, None, None, B, L, self.C1, out, nb=nb, flags=flags)
+        return out
+
+    def grad_w(self, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor] = None,
+               msplit: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
+        B, L = x0.size(0), x0.size(2)
+        plan = self.wg_plan()
+        n_wg = max(1, len(plan.items()) // 4)
+        da = conv_wgrad(plan, x0, x1, dy, dy2, self.M if msplit is None else msplit, B, L, self.M,
+                        wgrad_ksplit(B, L, n_wg))
+        dw0 = torch.zeros(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
+        dw1 = torch.zeros(self.M, self.C1, 1, device=x0.device, dtype=torch.float32) if self.C1 else None
+        unpack_weights(plan, self.M, da, dw0, self.s_w0(), dw1, self.s_w1())
+        return dw0, dw1
+
+
+# --------------------------------------------------------------------------------------------------
+# generic conv as an autograd op
+# --------------------------------------------------------------------------------------------------
+class ConvFn(torch.autograd.Function):
+    """Conv1d (optionally dilated / omni-scale-masked) — F.conv1d call sites of the hot path."""
+
+    @staticmethod
+    def forward(ctx, spec: ConvSpec, x: Tensor, w: Tensor, bias: Optional[Tensor]):
+        ctx.spec = spec
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return spec.forward(x, None, w, None, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec: ConvSpec = ctx.spec
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dx = spec.grad_x0(dy, w)
+        if ctx.needs_input_grad[2] and _want_weight_grad(spec):
+            dw, _ = spec.grad_w(x, None, dy)
+        if ctx.has_bias and ctx.needs_input_grad[3] and _want_weight_grad(spec):
+            db = row_sum(dy)
+        return None, dx, dw, db
+
+
+def conv1d(spec: ConvSpec, x: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tensor:
+    return ConvFn.apply(spec, x, w, bias)
+
+
+def mask_taps_(w: Tensor, lo: Tensor, hi: Tensor) -> None:
+    """W ← W ⊙ mask in place on ``w.data`` (OS_CNN.py:68 re-masks ``.data`` every forward)."""
+    lib = _lib.load()
+    M, C, K = w.shape
+    check(lib.fst_mask_taps(ptr(w), ptr(lo), ptr(hi), M, C, K, stream_ptr()), "fst_mask_taps")
+
+
+# --------------------------------------------------------------------------------------------------
+# BatchNorm1d (+ReLU, + second BN'd branch) over (B, L)
+# --------------------------------------------------------------------------------------------------
+def _bn_stats(y: Tensor, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tensor, training: bool, eps: float,
+              momentum: float) -> Tensor:
+    lib = _lib.load()
+    B, C, L = y.shape
+    stats = torch.empty(4 * C, device=y.device, dtype=torch.float32)
+    sums = None
+    if training:
+        sums = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
+        check(lib.fst_bn_stats(ptr(y), B, C, L, ptr(sums), stream_ptr()), "fst_bn_stats")
+    check(lib.fst_bn_finalize(ptr(sums), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), int(training), B, C, L, eps,
+                              momentum, ptr(stats), stream_ptr()), "fst_bn_finalize")
+    return stats
+
+
+def _bn_backward(dy: Tensor, y: Tensor, out: Optional[Tensor], stats: Tensor, relu: bool, training: bool,
+                 need_dx: bool = True):
+    lib = _lib.load()
+    B, C, L = y.shape
+    red = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
+    check(lib.fst_bn_bwd_reduce(ptr(dy), ptr(y), ptr(out), ptr(stats), B, C, L, int(relu), ptr(red), stream_ptr()),
+          "fst_bn_bwd_reduce")
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(y)
+        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(red), ptr(dx), B, C, L, int(relu),
+                                   int(training), stream_ptr()), "fst_bn_bwd_apply")
+    return dx, red[C:], red[:C]                                   # dx, dgamma, dbeta
+
+
+class BNActFn(torch.autograd.Function):
+    """BatchNorm1d (train: batch stats + running update; eval: running stats) → optional ReLU."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, rmean, rvar, training: bool, relu: bool, eps: float, momentum: float):
+        lib = _lib.load()
+        y = y.contiguous()
+        B, C, L = y.shape
+        stats = _bn_stats(y, gamma, beta, rmean, rvar, training, eps, momentum)
+        out = torch.empty_like(y)
+        check(lib.fst_bn_apply(ptr(y), ptr(stats), None, None, ptr(out), B, C, L, int(relu), stream_ptr()), "fst_bn_apply")
+        ctx.save_for_backward(y, out, stats)
+        ctx.relu, ctx.training = relu, training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, stats = ctx.saved_tensors
+        dx, dg, db = _bn_backward(dout.contiguous(), y, out if ctx.relu else None, stats, ctx.relu, ctx.training,
+                                  ctx.needs_input_grad[0])
+        return dx, dg, db, None, None, None, None, None, None
+
+
+class BNAddBNReluFn(torch.autograd.Function):
+    """relu(BN_a(ya) + BN_b(yb)) in one pass — the residual join of Res_OS_layer (OS_CNN.py:176-180)."""
+
+    @staticmethod
+    def forward(ctx, ya, ga, ba, rma, rva, yb, gb, bb, rmb, rvb, training: bool, eps: float, momentum: float):
+        lib = _lib.load()
+        ya, yb = ya.contiguous(), yb.contiguous()
+        B, C, L = ya.shape
+        sa = _bn_stats(ya, ga, ba, rma, rva, training, eps, momentum)
+        sb = _bn_stats(yb, gb, bb, rmb, rvb, training, eps, momentum)
+        out = torch.empty_like(ya)
+        check(lib.fst_bn_apply(ptr(ya), ptr(sa), ptr(yb), ptr(sb), ptr(out), B, C, L, 1, stream_ptr()), "fst_bn_apply")
+        ctx.save_for_backward(ya, yb, out, sa, sb)
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ya, yb, out, sa, sb = ctx.saved_tensors
+        dout = dout.contiguous()
+        dxa, dga, dba = _bn_backward(dout, ya, out, sa, True, ctx.training, ctx.needs_input_grad[0])
+        dxb, dgb, dbb = _bn_backward(dout, yb, out, sb, True, ctx.training, ctx.needs_input_grad[5])
+        return dxa, dga, dba, None, None, dxb, dgb, dbb, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# WaveGlow: WN stack, affine coupling
+# --------------------------------------------------------------------------------------------------
+class WNSpecs:
+    """Conv specs of one WN(n_in=h, n_layers, n_channels=n, k=3) (Simplified_NF_WaveGlow.py:55-99)."""
+
+    def __init__(self, h: int, n: int, n_layers: int = 8, kernel: int = 3):
+        self.h, self.n, self.n_layers, self.kernel = h, n, n_layers, kernel
+        self.start = ConvSpec(n, h)
+        self.ins = [ConvSpec(2 * n, n, kernel, 2 ** i, int((kernel * 2 ** i - 2 ** i) / 2), C1=h) for i in range(n_layers)]
+        self.rs = [ConvSpec(2 * n if i < n_layers - 1 else n, n) for i in range(n_layers)]
+        self.end = ConvSpec(2 * h, n)
+        # dacts = W_rsᵀ·[d_a ; d_out]: rows n, K = 2n channels from two tensors
+        self.rs_T = build_plan(n, [Segment(0, n, 0, 1), Segment(1, n, 0, 1)], 1, 1, 0, chunk_c=64)
+        self.rs_T_last = build_plan(n, [Segment(0, n, 0, 1)], 1, 1, 0, chunk_c=64)
+
+
+class WNFn(torch.autograd.Function):
+    """The whole gated dilated-conv stack (:101-123) as one autograd node.
+
+    Forward keeps, per layer, the layer input ``a_i``, the gate halves (tanh, sigmoid) and ``acts``;
+    the cond_layer 1x1 is folded into each in_layer GEMM as 25 extra K rows, so the [B, 2n·8, L]
+    conditioning tensor of the reference (1 GB at B=256, L=512) is never materialised.
+    ``u0`` may be a channel-slice view of a wider tensor (explicit batch stride).
+    Argument order after (specs, u0): start_w, start_b, cond_w, cond_b, end_w, end_b,
+    in_w[0..], in_b[0..], rs_w[0..], rs_b[0..]  — effective (weight-norm-folded) weights.
+    """
+
+    @staticmethod
+    def forward(ctx, specs: WNSpecs, u0: Tensor, *weights: Tensor):
+        lib = _lib.load()
+        S, nl = specs, specs.n_layers
+        start_w, start_b, cond_w, cond_b, end_w, end_b = weights[:6]
+        in_w, in_b = weights[6: 6 + nl], weights[6 + nl: 6 + 2 * nl]
+        rs_w, rs_b = weights[6 + 2 * nl: 6 + 3 * nl], weights[6 + 3 * nl: 6 + 4 * nl]
+        B, _, L = u0.shape
+        h, n = S.h, S.n
+        a = S.start.forward(u0, None, start_w, None, start_b)
+        out = torch.zeros(B, n, L, device=u0.device, dtype=torch.float32)
+        a_list, ts_list, acts_list = [a], [], []
+        bias_g = torch.stack(list(in_b)) + cond_b.view(nl, 2 * n)
+        for i in range(nl):
+            g = S.ins[i].forward(a, u0, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], bias_g[i])
+            acts = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
+            check(lib.fst_gate_fwd(ptr(g), ptr(acts), B, n, L, stream_ptr()), "fst_gate_fwd")
+            ts_list.append(g)
+            acts_list.append(acts)
+            if i < nl - 1:
+                a_next = torch.empty_like(a)
+                S.rs[i].forward(acts, None, rs_w[i], None, rs_b[i], y=a_next, res=a, y2=out, msplit=n, flags=EPI_ACC2)
+                a = a_next
+                a_list.append(a)
+            else:
+                S.rs[i].forward(acts, None, rs_w[i], None, rs_b[i], y=None, y2=out, msplit=0, flags=EPI_ACC2)
+        o = S.end.forward(out, None, end_w, None, end_b)
+        ctx.specs = S
+        ctx.save_for_backward(u0, out, *a_list, *ts_list, *acts_list, start_w, cond_w, end_w, *in_w, *rs_w)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        lib = _lib.load()
+        S: WNSpecs = ctx.specs
+        nl, h, n = S.n_layers, S.h, S.n
+        sv = ctx.saved_tensors
+        u0, out = sv[0], sv[1]
+        a_list, ts_list, acts_list = sv[2: 2 + nl], sv[2 + nl: 2 + 2 * nl], sv[2 + 2 * nl: 2 + 3 * nl]
+        start_w, cond_w, end_w = sv[2 + 3 * nl: 5 + 3 * nl]
+        in_w, rs_w = sv[5 + 3 * nl: 5 + 4 * nl], sv[5 + 4 * nl: 5 + 5 * nl]
+        need_w = any(ctx.needs_input_grad[2:]) and _want_weight_grad()
+        do = do.contiguous()
+        B, _, L = u0.shape
+        dev = u0.device
+
+        d_out = S.end.grad_x0(do, end_w)
+        d_end_w = d_end_b = None
+        if need_w:
+            d_end_w, _ = S.end.grad_w(out, None, do)
+            d_end_b = row_sum(do)
+        d_out_sum = row_sum(d_out) if need_w else None
+        d_u0 = torch.zeros(B, h, L, device=dev, dtype=torch.float32)
+        d_a: Optional[Tensor] = None
+        d_in_w, d_in_b, d_rs_w, d_rs_b = [None] * nl, [None] * nl, [None] * nl, [None] * nl
+        d_cond_w = torch.zeros_like(cond_w) if need_w else None
+        d_cond_b = torch.zeros(nl, 2 * n, device=dev, dtype=torch.float32) if need_w else None
+        for i in reversed(range(nl)):
+            last = i == nl - 1
+            # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
+            dacts = torch.empty(B, n, L, device=dev, dtype=torch.float32)
+            if last:
+                a_pk = pack_weights(S.rs_T_last, n, rs_w[i], (0, 1, n, 0))
+                conv_gemm(S.rs_T_last, a_pk, d_out, None, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0))
+            else:
+                a_pk = pack_weights(S.rs_T, n, rs_w[i], (0, 1, n, 0), rs_w[i], (n * n, 1, n, 0))
+                conv_gemm(S.rs_T, a_pk, d_a, d_out, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0))
+            if need_w:
+                if last:
+                    d_rs_w[i], _ = S.rs[i].grad_w(acts_list[i], None, d_out)
+                    d_rs_b[i] = d_out_sum
+                else:
+                    d_rs_w[i], _ = S.rs[i].grad_w(acts_list[i], None, d_a, d_out, msplit=n)
+                    d_rs_b[i] = torch.cat([row_sum(d_a), d_out_sum])
+            # ---- through the gate
+            dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
+            check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, stream_ptr()), "fst_gate_bwd")
+            if need_w:
+                dw0, dw1 = S.ins[i].grad_w(a_list[i], u0, dg)
+                d_in_w[i] = dw0
+                d_cond_w[2 * n * i: 2 * n * (i + 1)] = dw1
+                d_in_b[i] = row_sum(dg)
+                d_cond_b[i] = d_in_b[i]
+            # ---- into the layer input (residual path + dilated conv) and into the conditioning input
+            d_a = S.ins[i].grad_x0(dg, in_w[i], res=d_a)
+            S.ins[i].grad_x1(dg, cond_w[2 * n * i: 2 * n * (i + 1)], out=d_u0, flags=EPI_ACC1)
+        S.start.grad_x0(d_a, start_w, out=d_u0, flags=EPI_ACC1)
+        d_start_w = d_start_b = None
+        if need_w:
+            d_start_w, _ = S.start.grad_w(u0, None, d_a)
+            d_start_b = row_sum(d_a)
+            d_cond_b = d_cond_b.reshape(-1)
+        grads = [d_start_w, d_start_b, d_cond_w, d_cond_b, d_end_w, d_end_b, *d_in_w, *d_in_b, *d_rs_w, *d_rs_b]
+        return (None, d_u0 if ctx.needs_input_grad[1] else None, *grads)
+
+
+class CouplingFn(torch.autograd.Function):
+    """x_next = cat(u0, exp(log_s)·u1 + b) with (b, log_s) = split(o) (:173-178)."""
+
+    @staticmethod
+    def forward(ctx, u, o):
+        lib = _lib.load()
+        u, o = u.contiguous(), o.contiguous()
+        B, C, L = u.shape
+        xn = torch.empty_like(u)
+        check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, stream_ptr()), "fst_coupling_fwd")
+        ctx.save_for_backward(u, o)
+        return xn
+
+    @staticmethod
+    def backward(ctx, dxn):
+        lib = _lib.load()
+        u, o = ctx.saved_tensors
+        B, C, L = u.shape
+        du, d_o = torch.empty_like(u), torch.empty_like(o)
+        check(lib.fst_coupling_bwd(ptr(u), ptr(o), ptr(dxn.contiguous()), None, ptr(du), ptr(d_o), B, C // 2, L,
+                                   stream_ptr()), "fst_coupling_bwd")
+        return du, d_o
+
+
+class CouplingInvFn(torch.autograd.Function):
+    """x_next = cat(x0, (x1 − b)/exp(s)) (:193-196)."""
+
+    @staticmethod
+    def forward(ctx, x, o):
+        lib = _lib.load()
+        x, o = x.contiguous(), o.contiguous()
+        B, C, L = x.shape
+        xn = torch.empty_like(x)
+        check(lib.fst_coupling_inv_fwd(ptr(x), ptr(o), ptr(xn), B, C // 2, L, stream_ptr()), "fst_coupling_inv_fwd")
+        ctx.save_for_backward(xn, o)
+        return xn
+
+    @staticmethod
+    def backward(ctx, dxn):
+        lib = _lib.load()
+        xn, o = ctx.saved_tensors
+        B, C, L = xn.shape
+        dx, d_o = torch.empty_like(xn), torch.empty_like(o)
+        check(lib.fst_coupling_inv_bwd(ptr(xn), ptr(o), ptr(dxn.contiguous()), ptr(dx), ptr(d_o), B, C // 2, L,
+                                       stream_ptr()), "fst_coupling_inv_bwd")
+        return dx, d_o
+
+
+# --------------------------------------------------------------------------------------------------
+# CPC InfoNCE
+# --------------------------------------------------------------------------------------------------
+class CPCNceFn(torch.autograd.Function):
+    """nce = −(1/(B·T)) Σ_i Σ_b log_softmax(enc_i·pred_iᵀ)[b,b]; enc_i[b,c] = feat[b,c,t0+i] read in place."""
+
+    @staticmethod
+    def forward(ctx, feat: Tensor, pred: Tensor, t0: int, T: int):
+        lib = _lib.load()
+        _lib.require_gpu_tensor(feat, "feat")
+        feat, pred = feat.contiguous(), pred.contiguous()
+        B, C, L = feat.shape
+        assert pred.shape == (T, B, C) and t0 + T <= L
+        lse = torch.empty(T, B, device=feat.device, dtype=torch.float32)
+        acc = torch.zeros((), device=feat.device, dtype=torch.float32)
+        check(lib.fst_cpc_nce_fwd(feat.data_ptr() + 4 * t0, 1, C * L, L, ptr(pred), T, B, C, ptr(lse), ptr(acc),
+                                  stream_ptr()), "fst_cpc_nce_fwd")
+        ctx.save_for_backward(feat, pred, lse)
+        ctx.t0, ctx.T = t0, T
+        return acc * (-1.0 / (B * T))
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        feat, pred, lse = ctx.saved_tensors
+        B, C, L = feat.shape
+        T, t0 = ctx.T, ctx.t0
+        dfeat = torch.zeros_like(feat)
+        dpred = torch.empty_like(pred)
+        g = g.contiguous().float()
+        check(lib.fst_cpc_nce_bwd(feat.data_ptr() + 4 * t0, 1, C * L, L, ptr(pred), ptr(lse), T, B, C, ptr(g),
+                                  dfeat.data_ptr() + 4 * t0, ptr(dpred), stream_ptr()), "fst_cpc_nce_bwd")
+        return dfeat, dpred, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# CDAN random multilinear map: x[B, D] @ R[D, O] with R fixed
+# --------------------------------------------------------------------------------------------------
+class FixedMatmulFn(torch.autograd.Function):
+    """y = x @ R for a fixed (non-trainable) R — RandomLayer's big GEMM (C_DAN.py:21).  R is streamed
+    once through LDS as the B operand; x is packed as the A operand; K is split across workgroups."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, R: Tensor, Rt: Tensor):
+        x = x.contiguous()
+        Bx, D = x.shape
+        O = R.shape[1]
+        ctx.save_for_backward(Rt)
+        ctx.shape = (Bx, D, O)
+        return _fixed_matmul(x, R, Bx, D, O)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (Rt,) = ctx.saved_tensors
+        Bx, D, O = ctx.shape
+        return _fixed_matmul(dy.contiguous(), Rt, Bx, O, D), None, None
+
+
+_matmul_plans: Dict[Tuple[int, int], Plan] = {}
+
+
+def _fixed_matmul(x: Tensor, R: Tensor, M: int, K: int, N: int) -> Tensor:
+    """[M,K] @ [K,N] via the conv engine: rows = M, 'channels' = K, 'time' = N."""
+    key = (M, K)
+    if key not in _matmul_plans:
+        _matmul_plans[key] = build_plan(M, [Segment(0, K, 0, 1)], 1, 1, 0, chunk_c=32)
+    plan = _matmul_plans[key]
+    a = pack_weights(plan, M, x, (0, K, 1, 0))
+    n_tiles = (N + 127) // 128
+    ksplit = max(1, min(plan.n_chunks, 512 // max(1, n_tiles * plan.n_mgroups)))
+    y = torch.zeros(1, M, N, device=x.device, dtype=torch.float32)
+    conv_gemm(plan, a, R.view(1, K, N), None, None, 1, N, M, y, nb=1, ksplit=ksplit,
+              flags=EPI_ATOMIC if ksplit > 1 else 0)
+    return y.view(M, N)

@@ -1,0 +1,244 @@
+"""Train steps behind the reference's outer loop (train_and_test.py), built from the drop-in modules.
+
+* ``ClassifierTrainer`` — S1: FE → CLF → CE → backward → RMSprop×2 (train_and_test.py:148-171, no CPC term).
+* ``JointTrainer``      — S2: one batch of the joint phase incl. GradNorm (train_and_test.py:539-766).
+
+Differences from the reference are mechanical, not numerical:
+  - the double ``loss_total.backward()`` (quirk Q3) is reproduced by ONE backward of
+    Σ wᵢ·Lᵢ + 2·(a·cdan + b·fd_s + c·sl_t + d·sl_s) — same accumulated gradients, half the work;
+  - GradNorm's numpy round-trip (:694-711) stays on the device (same fp32 formulas, no host sync);
+  - per-batch ``.cpu()`` prints and feature dumps (:564-644) are not part of the step;
+  - during GradNorm's five partial backward passes only the shared OS_block needs weight gradients, so
+    every other conv skips its weight-gradient kernels (``ops.partial_backward``).
+Data parallelism: ``dist.GradBucket`` all-reduces one flat fp32 gradient bucket over RCCL.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .cdan import CDAN, RandomLayer
+from .cpc import CPC
+from .dist import GradBucket
+from .os_cnn import OS_CNN, OS_CNN_res, build_layer_with_layer_parameter
+from .structure import generate_layer_parameter_list, layer_parameter_list_input_change, out_channels
+from .waveglow import WaveGlow, WaveGlowLoss
+from .widgets import (AdversarialNetworkforCDAN, DimensionUnification, FeatureDiscriminatorforSource, NoiseTransfer,
+                      ProbTransfer, wgan_loss)
+
+MAX_KERNEL_SIZE = 89                                                          # train_and_test.py:40
+
+
+def specs_for(length: int, in_channel: int):
+    """(feature-extractor spec, classifier spec) exactly as train_and_test.py:38-53 derives them."""
+    budgets = [8 * 128 * in_channel, 5 * 128 * 256 + 2 * 256 * 128]
+    rf = min(int(length / 4), MAX_KERNEL_SIZE)
+    fe = generate_layer_parameter_list(1, rf, budgets, in_channel)
+    return fe, layer_parameter_list_input_change(fe, out_channels(fe[-1]))
+
+
+def loss_coefficients(epoch: int) -> Tuple[float, float, float, float]:
+    """(cdan, fd_s, sl_t, sl_s) coefficients by epoch (train_and_test.py:665-672)."""
+    if epoch < 12:
+        return 3, 3, 2, 2
+    if epoch < 24:
+        return 2, 3, 1.8, 1.5
+    if epoch < 50:
+        return 1.5, 2, 1.8, 1.8
+    return 1.5, 1.5, 2.5, 2.5
+
+
+class ClassifierTrainer:
+    def __init__(self, length: int, in_channel: int, n_class: int, device, bucket: Optional[GradBucket] = None):
+        fe_spec, clf_spec = specs_for(length, in_channel)
+        self.fe = OS_CNN_res(fe_spec).to(device)
+        self.clf = OS_CNN(clf_spec, n_class).to(device)
+        self.opt_fe = torch.optim.RMSprop(self.fe.parameters(), lr=0.001)
+        self.opt_clf = torch.optim.RMSprop(self.clf.parameters(), lr=0.003)
+        self.bucket = bucket
+        self.fe.train(); self.clf.train()
+
+    def parameters(self) -> List[nn.Parameter]:
+        return list(self.fe.parameters()) + list(self.clf.parameters())
+
+    def step(self, x: torch.Tensor, y: torch.Tensor):
+        logits, _ = self.clf(self.fe(x))
+        loss = F.cross_entropy(logits, y)
+        loss.backward()
+        if self.bucket is not None:
+            self.bucket.all_reduce(self.parameters())
+        self.opt_fe.step(); self.opt_clf.step()
+        self.opt_fe.zero_grad(set_to_none=True); self.opt_clf.zero_grad(set_to_none=True)
+        return loss.detach(), logits.detach()
+
+
+@dataclass
+class JointConfig:
+    L_t: int = 512
+    C_in_t: int = 1
+    L_s: int = 512
+    C_in_s: int = 1
+    n_class_t: int = 4
+    n_class_s: int = 4
+    nf_flows: int = 3                                                         # WaveGlow(3, C, 120) :71
+    nf_channels: int = 120
+    cpc_hidden: int = 64                                                      # CPC(C, 64, L//2) :131
+    cdan_dim: int = 1024                                                      # :75-77
+    ad_hidden: int = 1024
+    dropout_p: float = 0.2
+    nf_end_std: float = 0.0       # >0: draw WN.end (zero-init in the reference) so the flow is non-degenerate
+
+
+class JointTrainer:
+    MODULES = ("fe_t", "clf_t", "fe_s", "dimunif", "clf_s", "probtransfer", "nf", "noise", "ad_net", "fd_s", "cpc")
+    LRS = {"fe_t": 0.001, "clf_t": 0.003, "fe_s": 0.001, "dimunif": 0.001, "clf_s": 0.003, "probtransfer": 0.001,
+           "nf": 0.001, "noise": 0.005, "ad_net": 0.001, "fd_s": 0.001}       # train_and_test.py:97-106
+
+    def __init__(self, cfg: JointConfig, device, bucket: Optional[GradBucket] = None, fe_t_spec=None, clf_spec=None,
+                 fe_s_spec=None):
+        self.cfg, self.device, self.bucket = cfg, device, bucket
+        if fe_t_spec is None:
+            fe_t_spec, clf_spec = specs_for(cfg.L_t, cfg.C_in_t)
+            fe_s_spec, _ = specs_for(cfg.L_s, cfg.C_in_s)
+        C, C_s = out_channels(fe_t_spec[-1]), out_channels(fe_s_spec[-1])
+        m: Dict[str, nn.Module] = {}
+        m["fe_t"] = OS_CNN_res(fe_t_spec)
+        m["clf_t"] = OS_CNN(clf_spec, cfg.n_class_t)
+        m["fe_s"] = OS_CNN_res(fe_s_spec)
+        m["dimunif"] = DimensionUnification(C_s, C, cfg.L_s, cfg.L_t)
+        m["clf_s"] = OS_CNN(clf_spec, cfg.n_class_s)
+        m["probtransfer"] = ProbTransfer(m["clf_s"].length_before_classification)
+        m["nf"] = WaveGlow(cfg.nf_flows, C, cfg.nf_channels)
+        if cfg.nf_end_std > 0:
+            for wn in m["nf"].WN:
+                wn.end.weight.data.normal_(0, cfg.nf_end_std)
+                wn.end.bias.data.normal_(0, cfg.nf_end_std)
+        m["noise"] = NoiseTransfer(C, cfg.L_t)
+        self.random_layer = RandomLayer([C * cfg.L_t, cfg.n_class_t], cfg.cdan_dim)
+        m["ad_net"] = AdversarialNetworkforCDAN(cfg.cdan_dim, cfg.ad_hidden)
+        m["ad_net"].dropout1.p = m["ad_net"].dropout2.p = cfg.dropout_p
+        m["fd_s"] = FeatureDiscriminatorforSource(m["clf_s"].length_before_classification)
+        m["cpc"] = CPC(C, cfg.cpc_hidden, cfg.L_t // 2)
+        self.m = {k: v.to(device) for k, v in m.items()}
+        self.random_layer = self.random_layer.to(device)
+        self.nf_loss = WaveGlowLoss()
+        self.opts = {k: torch.optim.RMSprop(self.m[k].parameters(), lr=lr) for k, lr in self.LRS.items()}
+        self.opt_cpc = torch.optim.Adam(self.m["cpc"].parameters(), lr=0.002)
+        self.w_t = nn.Parameter(torch.tensor([2.0, 5.0], device=device))         # :501-505
+        self.w_s = nn.Parameter(torch.tensor([2.0, 2.0, 4.0], device=device))
+        self.opt_w_t = torch.optim.Adam([self.w_t], lr=0.0002)
+        self.opt_w_s = torch.optim.Adam([self.w_s], lr=0.001)
+        self.init_t = self.init_s = None
+        self.alpha = 3
+        self.on_grads_ready = None                                            # test hook: called before the optimisers step
+        for mod in self.m.values():
+            mod.train()
+        # GradNorm differentiates the shared OS_blocks only: their convs keep weight gradients in partial passes
+        for key in ("fe_t", "fe_s"):
+            for layer in self.m[key].return_last_layer().layer_list:
+                layer.spec.always_weight_grad = True
+
+    # ------------------------------------------------------------------ helpers
+    def parameters(self) -> List[nn.Parameter]:
+        return [p for k in self.MODULES for p in self.m[k].parameters()]
+
+    def load_params(self, mods: Dict[str, Dict[str, torch.Tensor]], mats=None) -> None:
+        """Load per-module state (reference state_dict key names) — used by the parity tests."""
+        for k, sd in mods.items():
+            self.m[k].load_state_dict({n: v.detach().to(self.device) for n, v in sd.items()})
+        if mats is not None:
+            self.random_layer.random_matrix = [t.to(self.device) for t in mats]
+            self.random_layer._transposed = {}
+
+    # ------------------------------------------------------------------ forward (train_and_test.py:547-603)
+    def forward_losses(self, x_t, y_t, x_s, y_s, t_samples=(None, None)):
+        m = self.m
+        feat_t = m["fe_t"](x_t)
+        sl_t = m["cpc"](feat_t, t_samples[0])
+        feat_s = m["dimunif"](m["fe_s"](x_s))
+        sl_s = m["cpc"](feat_s, t_samples[1])
+        out_t, out_s = m["nf"](feat_t), m["nf"](feat_s)
+        nf_t, nf_s = self.nf_loss(out_t), self.nf_loss(out_s)
+        z_s2t = m["noise"](out_t[0], out_s[0])
+        feat_s2t = m["nf"].infer(z_s2t)
+        logit_t, pool_t = m["clf_t"](feat_t)
+        m["clf_t"].eval()                                                     # :584-586
+        logit_s2t, pool_s2t = m["clf_t"](feat_s2t)
+        m["clf_t"].train()
+        logit_s, pool_s = m["clf_s"](feat_s)
+        ce_t, ce_s = F.cross_entropy(logit_t, y_t), F.cross_entropy(logit_s, y_s)
+        cdan = CDAN(feat_t, feat_s2t, logit_t, logit_s2t, m["ad_net"], self.random_layer)
+        tr_t, tr_s2t = m["probtransfer"](pool_t), m["probtransfer"](pool_s2t)
+        ce_s2t2s = F.cross_entropy(m["clf_s"].hidden(tr_s2t), y_s)
+        fd = wgan_loss(m["fd_s"](tr_t), m["fd_s"](tr_s2t), m["fd_s"](pool_s))
+        losses = {"nf_t": nf_t, "nf_s": nf_s, "ce_t": ce_t, "sl_t": sl_t, "ce_s": ce_s, "sl_s": sl_s, "cdan": cdan,
+                  "ce_s2t2s": ce_s2t2s, "fd_s": fd}
+        aux = {"logit_t": logit_t, "logit_s": logit_s, "logit_s2t": logit_s2t, "feat_t": feat_t, "feat_s2t": feat_s2t}
+        return losses, aux
+
+    # ------------------------------------------------------------------ one optimisation step (:645-766)
+    def step(self, x_t, y_t, x_s, y_s, epoch: int = 0, t_samples=(None, None)):
+        L, aux = self.forward_losses(x_t, y_t, x_s, y_s, t_samples)
+        lt = torch.stack([L["nf_t"], L["ce_t"]])
+        ls = torch.stack([L["nf_s"], L["ce_s"], L["ce_s2t2s"]])
+        lt_v, ls_v = lt.detach(), ls.detach()
+        if self.bucket is not None:                                           # keep GradNorm identical on all ranks
+            lt_v, ls_v = self.bucket.mean_scalars(lt_v), self.bucket.mean_scalars(ls_v)
+        if self.init_t is None:                                               # :658-664
+            self.init_t, self.init_s = torch.sigmoid(lt_v), torch.sigmoid(ls_v)
+        a, b, c, d = loss_coefficients(epoch)
+        # Q3: first backward + second backward (weights zeroed) == Σ wᵢ∇Lᵢ + 2·(a∇cdan + b∇fd + c∇sl_t + d∇sl_s)
+        total = torch.sum(self.w_t.detach() * lt) + torch.sum(self.w_s.detach() * ls) \
+            + 2.0 * (a * L["cdan"] + b * L["fd_s"] + c * L["sl_t"] + d * L["sl_s"])
+        for o in self.opts.values():
+            o.zero_grad(set_to_none=True)
+        self.opt_cpc.zero_grad(set_to_none=True)
+        total.backward(retain_graph=True)
+
+        # ---- GradNorm (:682-715): per-loss gradient norms over the 12 shared tensors
+        sh_t = list(self.m["fe_t"].return_last_layer().parameters())
+        sh_s = list(self.m["fe_s"].return_last_layer().parameters())
+        with ops.partial_backward():
+            g_t = [torch.autograd.grad(lt[i], sh_t, retain_graph=True) for i in range(2)]
+            g_s = [torch.autograd.grad(ls[i], sh_s, retain_graph=(i < 2)) for i in range(3)]
+        base_t = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_t])
+        base_s = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_s])
+        if self.bucket is not None:
+            base_t, base_s = self.bucket.mean_scalars(base_t), self.bucket.mean_scalars(base_s)
+        # ‖wᵢ·g‖ = |wᵢ|·‖g‖, so the norms are differentiable functions of w alone
+        nt, ns = torch.abs(self.w_t) * base_t, torch.abs(self.w_s) * base_s
+        ratio_t, ratio_s = torch.sigmoid(lt_v) / self.init_t, torch.sigmoid(ls_v) / self.init_s
+        inv_t, inv_s = ratio_t / ratio_t.mean(), ratio_s / ratio_s.mean()
+        const_t = (nt.detach().mean() * inv_t ** self.alpha).detach()
+        const_s = (ns.detach().mean() * inv_s ** self.alpha).detach()
+        g_w_t = torch.autograd.grad(torch.sum(torch.abs(nt - const_t)), self.w_t)[0]
+        g_w_s = torch.autograd.grad(torch.sum(torch.abs(ns - const_s)), self.w_s)[0]
+
+        if self.bucket is not None:
+            self.bucket.all_reduce(self.parameters())
+        self.w_t.grad, self.w_s.grad = g_w_t, g_w_s
+        if self.on_grads_ready is not None:
+            self.on_grads_ready()
+        self.opt_w_t.step(); self.opt_w_s.step()
+        for o in self.opts.values():
+            o.step()
+        self.opt_cpc.step()
+        with torch.no_grad():                                                 # :756-766
+            self.w_t.clamp_(min=0.0)
+            self.w_t.mul_(7 / torch.sum(self.w_t))
+            self.w_s.clamp_(min=0.0)
+            self.w_s.mul_(8 / torch.sum(self.w_s))
+            for p in self.m["ad_net"].parameters():
+                p.clamp_(-0.0005, 0.0005)
+            for p in self.m["fd_s"].parameters():
+                p.clamp_(-0.01, 0.01)
+        report = {k: v.detach() for k, v in L.items()}
+        report.update({k: v.detach() for k, v in aux.items()})
+        report.update({"w_t": self.w_t.detach().clone(), "w_s": self.w_s.detach().clone(),
+                       "norms_t": nt.detach(), "norms_s": ns.detach()})
+        return report

@@ -1,0 +1,133 @@
+"""Drop-in simplified WaveGlow (constructor / forward / infer / state_dict surface of the reference's
+Simplified_NF_WaveGlow.py) on the HIP conv engine.
+
+Per flow: invertible 1x1 conv (MFMA GEMM over channels) → WN on the first half of the channels (one
+autograd node, ops.WNFn) → affine coupling (one pointwise kernel).  ``weight_norm``-wrapped ``nn.Conv1d``
+objects are parameter containers only (old-style ``weight_g`` / ``weight_v`` names, as in the reference);
+the effective weights g·v/‖v‖ are folded once per call and handed to the kernels.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Invertible1x1Conv(nn.Module):
+    """z = W·x per timestep, log_det = B·L·logdet(W); reverse uses an inverse computed ONCE and cached
+    without gradient (quirk Q2, Simplified_NF_WaveGlow.py:24-42)."""
+
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = nn.Conv1d(c, c, kernel_size=1, stride=1, padding=0, bias=False)
+        W = torch.linalg.qr(torch.FloatTensor(c, c).normal_())[0]          # random orthonormal init (:17)
+        if torch.det(W) < 0:
+            W[:, 0] = -1 * W[:, 0]
+        self.conv.weight.data = W.contiguous().view(c, c, 1)
+        self.spec = ops.ConvSpec(c, c)
+
+    def forward(self, z: torch.Tensor, reverse: bool = False):
+        batch_size, _, n_of_groups = z.size()
+        if reverse:
+            if not hasattr(self, "W_inverse"):
+                self.W_inverse = self.conv.weight.detach().squeeze().float().inverse()[..., None].contiguous()
+            return ops.conv1d(self.spec, z.contiguous(), self.W_inverse, None)
+        W = self.conv.weight
+        log_det_W = batch_size * n_of_groups * torch.logdet(W.squeeze())
+        return ops.conv1d(self.spec, z.contiguous(), W, None), log_det_W
+
+
+def _wn_conv(cin: int, cout: int, k: int, **kw) -> nn.Conv1d:
+    return nn.utils.weight_norm(nn.Conv1d(cin, cout, k, **kw), name="weight")
+
+
+def _folded(conv: nn.Conv1d) -> torch.Tensor:
+    return torch._weight_norm(conv.weight_v, conv.weight_g, 0)
+
+
+class WN(nn.Module):
+    """Gated dilated-conv stack conditioned on its own input (Simplified_NF_WaveGlow.py:55-123)."""
+
+    def __init__(self, n_in_channels: int, n_layers: int, n_channels: int, kernel_size: int):
+        super().__init__()
+        self.n_layers, self.n_channels = n_layers, n_channels
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        self.start = _wn_conv(n_in_channels, n_channels, 1)
+        end = nn.Conv1d(n_channels, 2 * n_in_channels, 1)
+        end.weight.data.zero_()                                            # coupling starts as identity (:73-77)
+        end.bias.data.zero_()
+        self.end = end
+        self.cond_layer = _wn_conv(n_in_channels, 2 * n_channels * n_layers, 1)
+        for i in range(n_layers):
+            d = 2 ** i
+            self.in_layers.append(_wn_conv(n_channels, 2 * n_channels, kernel_size, dilation=d,
+                                           padding=int((kernel_size * d - d) / 2)))
+            self.res_skip_layers.append(_wn_conv(n_channels, 2 * n_channels if i < n_layers - 1 else n_channels, 1))
+        self.specs = ops.WNSpecs(n_in_channels, n_channels, n_layers, kernel_size)
+
+    def folded_weights(self) -> List[torch.Tensor]:
+        w = [_folded(self.start), self.start.bias, _folded(self.cond_layer), self.cond_layer.bias,
+             self.end.weight, self.end.bias]
+        w += [_folded(l) for l in self.in_layers] + [l.bias for l in self.in_layers]
+        w += [_folded(l) for l in self.res_skip_layers] + [l.bias for l in self.res_skip_layers]
+        return w
+
+    def forward(self, forward_input: torch.Tensor) -> torch.Tensor:
+        return ops.WNFn.apply(self.specs, forward_input, *self.folded_weights())
+
+
+class WaveGlow(nn.Module):
+    """``n_flows`` × {invertible 1x1, WN, affine coupling} (Simplified_NF_WaveGlow.py:125-203)."""
+
+    def __init__(self, n_flows: int, n_group: int, n_channels_for_WN: int):
+        super().__init__()
+        assert n_group % 2 == 0
+        self.n_flows, self.n_group = n_flows, n_group
+        self.WN = nn.ModuleList()
+        self.convinv = nn.ModuleList()
+        for _ in range(n_flows):
+            self.convinv.append(Invertible1x1Conv(n_group))
+            self.WN.append(WN(n_group // 2, 8, n_channels_for_WN, 3))
+
+    def forward(self, forward_input: torch.Tensor):
+        audio = forward_input
+        log_s_list, log_det_W_list = [], []
+        n_half = self.n_group // 2
+        for k in range(self.n_flows):
+            audio, log_det_W = self.convinv[k](audio)
+            log_det_W_list.append(log_det_W)
+            output = self.WN[k](audio[:, :n_half, :])
+            log_s_list.append(output[:, n_half:, :])
+            audio = ops.CouplingFn.apply(audio, output)
+        return audio, log_s_list, log_det_W_list
+
+    def infer(self, audio: torch.Tensor, sigma: float = 1.0) -> torch.Tensor:
+        n_half = self.n_group // 2
+        for k in reversed(range(self.n_flows)):
+            audio = audio.contiguous()
+            output = self.WN[k](audio[:, :n_half, :])
+            audio = ops.CouplingInvFn.apply(audio, output)
+            audio = self.convinv[k](audio, reverse=True)
+        return audio
+
+
+class WaveGlowLoss(nn.Module):
+    """(Σz²/2σ² − Σlog_s − Σlog_det_W) / (B·C·L) (Simplified_NF_WaveGlow.py:223-241)."""
+
+    def __init__(self, sigma: float = 1.0):
+        super().__init__()
+        self.sigma = sigma
+
+    def forward(self, model_output):
+        z, log_s_list, log_det_W_list = model_output
+        log_s_total = log_s_list[0].sum()
+        log_det_W_total = log_det_W_list[0]
+        for log_s, log_det in zip(log_s_list[1:], log_det_W_list[1:]):
+            log_s_total = log_s_total + log_s.sum()
+            log_det_W_total = log_det_W_total + log_det
+        loss = torch.sum(z * z) / (2 * self.sigma * self.sigma) - log_s_total - log_det_W_total
+        return loss / (z.size(0) * z.size(1) * z.size(2))

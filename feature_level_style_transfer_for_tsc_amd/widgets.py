@@ -1,0 +1,153 @@
+"""Drop-in small heads (surface of the reference's widgets.py).  These are a few hundred kFLOP per
+sample; they stay stock torch ops (rocBLAS / MIOpen RNN) except the two 1x1 convs over [B, C, L]
+tensors, which use the conv engine."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cdan import calc_coeff as _calc_coeff_cdan, grl_hook
+
+
+def calc_coeff(iter_num, high=1.0, low=0.0, alpha=2.0, max_iter=50.0):
+    return _calc_coeff_cdan(iter_num, high, low, alpha, max_iter)
+
+
+class _GRLCounter:
+    """Gradient-reversal coefficient driven by a per-CALL counter saturating at ``max_iter`` (Q7)."""
+
+    def _init_grl(self):
+        self.iter_num = -1
+        self.alpha, self.low, self.high, self.max_iter = 100.0, 0.0, 1.0, 20.0
+
+    def _next_coeff(self) -> float:
+        if self.training:
+            self.iter_num += 1
+        if self.iter_num >= self.max_iter:
+            self.iter_num = self.max_iter
+        return calc_coeff(self.iter_num, self.high, self.low, self.alpha, self.max_iter)
+
+
+class FeatureDiscriminatorforSource(nn.Module, _GRLCounter):
+    """GRL → 4-layer LeakyReLU MLP (widgets.py:15-42)."""
+
+    def __init__(self, length_of_feature):
+        super().__init__()
+        self.model = nn.Sequential(nn.Linear(length_of_feature, 800), nn.LeakyReLU(0.2), nn.Linear(800, 400),
+                                   nn.LeakyReLU(0.2), nn.Linear(400, 50), nn.LeakyReLU(0.2), nn.Linear(50, 1))
+        self._init_grl()
+
+    def forward(self, probs):
+        coeff = self._next_coeff()
+        probs = probs * 1.0
+        probs.register_hook(grl_hook(coeff))
+        return self.model(probs)
+
+
+class ProbTransfer(nn.Module):
+    """LSTM over the pooled feature repeated twice; returns h_n (widgets.py:46-55)."""
+
+    def __init__(self, num_of_channels):
+        super().__init__()
+        self.model = nn.LSTM(input_size=num_of_channels, hidden_size=num_of_channels, batch_first=True)
+
+    def forward(self, features_of_target_before_linear):
+        x = torch.unsqueeze(features_of_target_before_linear, 1)
+        _, (h_n, _) = self.model(torch.cat((x, x), dim=1))
+        return torch.squeeze(h_n, dim=0)
+
+
+def wgan_loss(values_from_target_side, values_from_s2t2s, values_from_source_side):
+    return -torch.mean(values_from_target_side) - torch.mean(values_from_s2t2s) + torch.mean(values_from_source_side)
+
+
+class DimensionUnification(nn.Module):
+    """ReLU(Linear over time) → ReLU(1x1 conv over channels) (widgets.py:66-78)."""
+
+    def __init__(self, source_channel, target_channel, source_length, target_length):
+        super().__init__()
+        self.length_unification = nn.Linear(in_features=source_length, out_features=target_length)
+        self.relu1 = nn.ReLU()
+        self.channel_unification = nn.Conv1d(in_channels=source_channel, out_channels=target_channel, kernel_size=1)
+        self.relu2 = nn.ReLU()
+        self.spec = ops.ConvSpec(target_channel, source_channel)
+
+    def forward(self, source_feature):
+        h = self.relu1(self.length_unification(source_feature))
+        h = ops.conv1d(self.spec, h.contiguous(), self.channel_unification.weight, self.channel_unification.bias)
+        return self.relu2(h)
+
+
+def init_weights(m):
+    name = m.__class__.__name__
+    if name.find('Conv2d') != -1 or name.find('ConvTranspose2d') != -1:
+        nn.init.kaiming_uniform_(m.weight)
+        nn.init.zeros_(m.bias)
+    elif name.find('BatchNorm') != -1:
+        nn.init.normal_(m.weight, 1.0, 0.02)
+        nn.init.zeros_(m.bias)
+    elif name.find('Linear') != -1:
+        nn.init.xavier_normal_(m.weight)
+        nn.init.zeros_(m.bias)
+
+
+class AdversarialNetworkforCDAN(nn.Module, _GRLCounter):
+    """GRL → Linear-ReLU-Dropout ×2 → Linear(1) (widgets.py:95-131); ``coeff`` is read by CDAN()."""
+
+    def __init__(self, in_feature, hidden_size):
+        super().__init__()
+        self.ad_layer1 = nn.Linear(in_feature, hidden_size)
+        self.ad_layer2 = nn.Linear(hidden_size, hidden_size)
+        self.ad_layer3 = nn.Linear(hidden_size, 1)
+        self.relu1, self.relu2 = nn.ReLU(), nn.ReLU()
+        self.dropout1, self.dropout2 = nn.Dropout(0.2), nn.Dropout(0.2)
+        self.apply(init_weights)
+        self._init_grl()
+        self.coeff = float(0.001)
+
+    def forward(self, x):
+        coeff = self._next_coeff()
+        self.coeff = coeff
+        x = x * 1.0
+        x.register_hook(grl_hook(coeff))
+        x = self.dropout1(self.relu1(self.ad_layer1(x)))
+        x = self.dropout2(self.relu2(self.ad_layer2(x)))
+        return self.ad_layer3(x)
+
+
+class NoiseTransfer(nn.Module):
+    """Latent mean-shift "style transfer" (widgets.py:136-167) with the reference's stateful, detached
+    running sums (Q5: they are not averages — ``avg += (B/N_seen)·mean(batch)``)."""
+
+    def __init__(self, noise_channel, length_of_noise, with_nvidia=True):
+        super().__init__()
+        self.apply_learnable_weight = nn.Conv1d(noise_channel, noise_channel, 1)
+        self.activation_selu = nn.SELU()
+        self.target_avg = torch.zeros([noise_channel, length_of_noise]).float()
+        self.source_avg = torch.zeros([noise_channel, length_of_noise]).float()
+        self.time = 0
+        self.cal_num_target = 0
+        self.cal_num_source = 0
+
+    def _apply(self, fn, *a, **k):
+        self.target_avg, self.source_avg = fn(self.target_avg), fn(self.source_avg)
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, target_noise_batch, source_noise_batch):
+        self.time += 1
+        bt, bs = target_noise_batch.size(0), source_noise_batch.size(0)
+        if self.time == 1:
+            self.target_avg = self.target_avg + torch.mean(target_noise_batch, dim=0)
+            self.source_avg = self.source_avg + torch.mean(source_noise_batch, dim=0)
+        else:
+            self.target_avg = self.target_avg + (bt / self.cal_num_target) * torch.mean(target_noise_batch, dim=0)
+            self.source_avg = self.source_avg + (bs / self.cal_num_source) * torch.mean(source_noise_batch, dim=0)
+        self.cal_num_target += bt
+        self.cal_num_source += bs
+        general_distance = self.target_avg - self.source_avg
+        learned = self.activation_selu(self.apply_learnable_weight(general_distance))   # unbatched [C, L] conv
+        self.source_avg = self.source_avg.detach()
+        self.target_avg = self.target_avg.detach()
+        return learned + source_noise_batch

@@ -1,0 +1,159 @@
+/* libfst_hip.so — C ABI of the MI355X (gfx950) train-step kernels for the feature-level
+ * style-transfer TSC hot path.
+ *
+ * The reference (BaeHann/feature_level_style_transfer_for_TSC) has no FFI: its hot path is stock
+ * PyTorch ops called from nn.Modules.  Each entry point below names the reference call site it
+ * replaces (file:line, relative to the reference root).  The Python host side
+ * (feature_level_style_transfer_for_tsc_amd/_lib.py) binds exactly these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory;
+ *     the library never allocates, frees or retains device memory;
+ *   - activations are fp32, NCL, channel stride = L, explicit batch stride (so channel slices of a
+ *     wider tensor can be passed without a copy);
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*); no implicit syncs;
+ *   - return 0 on success, <0 for an argument error detected on the host before any launch,
+ *     >0 = hipError_t; fst_last_error() returns a thread-local message.  No exceptions cross the ABI.
+ */
+#ifndef FST_HIP_H
+#define FST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FST_ABI_VERSION 1
+
+int fst_version(void);
+const char* fst_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Conv plan.  A "plan" is a small int32 device table describing how a (multi-tap, optionally
+ * dilated, optionally two-input) 1-D convolution is cut into K-chunks and 32-row M-blocks for the
+ * f32 MFMA implicit GEMM.  It is built on the host (plan.py) once per layer shape.
+ *
+ *   plan[0..7]   header: n_chunks, n_mgroups, MB (32-row blocks per M-group), ntaps, dil, pad_left,
+ *                        chunk_cap (max padded channels per chunk, even), total_records
+ *   plan[8 + 4*q ...]                 chunk q:        src (0|1), c_begin, c_count, 0
+ *   plan[8 + 4*n_chunks + 4*(g*n_chunks+q) ...]  (g,q): tap_lo, tap_hi, record_offset, 0
+ *
+ * A "record" is MB*64 floats: for one (tap, channel pair) the MB A-operand registers of one
+ * v_mfma_f32_32x32x2_f32 k-step (lane l ↔ row l&31 of the block, channel parity l>>5).
+ * ------------------------------------------------------------------------------------------- */
+#define FST_PLAN_HEADER 8
+
+/* Weight source description for pack/unpack: element (m, c, tap) of input `s` lives at
+ * w[s][off0 + m*sm + c*sc + tap*st].  Forward convs use (sm, sc, st) = (C*ntaps, ntaps, 1);
+ * the data-gradient conv uses the transposed, tap-flipped view of the same tensor. */
+typedef struct {
+  const float* w;   /* device */
+  int64_t off0, sm, sc, st;
+} fst_wsrc;
+
+/* Pack PyTorch-layout weights into the plan's record layout.  Replaces the implicit weight use in
+ * F.conv1d at OS_CNN/OS_CNN.py:71, Simplified_NF_WaveGlow.py:36,41,103,107,112,116,123. */
+int fst_pack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
+                     const fst_wsrc* src0_host, const fst_wsrc* src1_host,
+                     int M, float* a_packed, void* stream);
+
+/* Inverse of fst_pack_weights for weight gradients: scatter a packed gradient back to PyTorch
+ * layout (dw0/dw1 must be zero-filled by the caller when the plan does not cover every tap). */
+int fst_unpack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
+                       const float* a_packed, int M,
+                       float* dw0, int64_t off0_0, int64_t sm0, int64_t sc0, int64_t st0,
+                       float* dw1, int64_t off0_1, int64_t sm1, int64_t sc1, int64_t st1,
+                       void* stream);
+
+/* Omni-scale re-masking W ← W ⊙ mask, mask given as per-output-channel live tap range.
+ * Replaces OS_CNN/OS_CNN.py:68. */
+int fst_mask_taps(float* w, const int32_t* live_lo, const int32_t* live_hi, int M, int C, int K, void* stream);
+
+/* y[b,m,t] = bias[m] + Σ_k A[m,k]·xcol[b,k,t]  — the forward engine (f32 MFMA, LDS-staged input
+ * window).  Rows m < msplit go to y (+res if given); rows ≥ msplit go to y2 (accumulated if
+ * FST_EPI_ACC2).  Replaces F.conv1d/nn.Conv1d at OS_CNN/OS_CNN.py:71,164 and
+ * Simplified_NF_WaveGlow.py:36,41,103,107,112,116,123; with transposed packing it is also the
+ * data-gradient conv of every one of those.
+ *   flags: FST_EPI_RELU, FST_EPI_ACC2, FST_EPI_ATOMIC (ksplit>1; y must be pre-initialised) */
+#define FST_EPI_RELU   1
+#define FST_EPI_ACC2   2
+#define FST_EPI_ATOMIC 4
+#define FST_EPI_ACC1   8
+int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs,
+                  const float* a_packed, const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
+                  const float* bias,
+                  float* y, int64_t y_bs, const float* res, int64_t res_bs,
+                  float* y2, int64_t y2_bs, int msplit,
+                  int B, int L, int M, int nb_cfg, int ksplit, int flags, void* stream);
+
+/* dA_packed[(g,q) records] += Σ_{b,t} dy[b,m,t]·xcol[b,k,t]  — weight-gradient engine (f32 MFMA,
+ * split over (b,t) with fp32 atomics; the caller zero-fills da_packed).  Replaces the weight
+ * gradient autograd derives for every conv listed above (Q1: with a dense plan it also yields the
+ * masked-tap gradients the reference's GradNorm consumes, train_and_test.py:685-690). */
+int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs,
+                   const float* dy, int64_t dy_bs, const float* dy2, int64_t dy2_bs, int msplit,
+                   float* da_packed, const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
+                   int B, int L, int M, int ksplit, void* stream);
+
+/* out[m] (+)= Σ_{b,t} x[b,m,t]   (bias gradients; BN β gradient). */
+int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm1d over (B, L), train and eval — replaces nn.BatchNorm1d at OS_CNN/OS_CNN.py:72,165
+ * and the ReLU / residual add at :74, :179.
+ * stats layout (float[4*C]): mean | invstd | scale | shift   (scale = γ·invstd, shift = β − mean·scale)
+ * ------------------------------------------------------------------------------------------- */
+int fst_bn_stats(const float* y, int B, int C, int L, float* sums /* [2*C], zeroed by caller */, void* stream);
+int fst_bn_finalize(const float* sums, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int train,
+                    int B, int C, int L, float eps, float momentum, float* stats, void* stream);
+/* out = act(y*scale + shift (+ res*res_scale + res_shift | + res)) */
+int fst_bn_apply(const float* y, const float* stats, const float* res, const float* res_stats,
+                 float* out, int B, int C, int L, int relu, void* stream);
+/* reductions for backward: red[c] = Σ dyʹ, red[C+c] = Σ dyʹ·x̂, with dyʹ = dy·[out>0] when relu */
+int fst_bn_bwd_reduce(const float* dy, const float* y, const float* out, const float* stats,
+                      int B, int C, int L, int relu, float* red /* [2*C] zeroed */, void* stream);
+/* dx = scale·(dyʹ − red0/N − x̂·red1/N) in train mode, scale·dyʹ in eval mode */
+int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
+                     float* dx, int B, int C, int L, int relu, int train, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * WaveGlow pieces — Simplified_NF_WaveGlow.py
+ * ------------------------------------------------------------------------------------------- */
+/* gate (:44-54): g[B,2n,L] → t=tanh(g[:n]), s=sigmoid(g[n:]) written back over g; acts=t·s */
+int fst_gate_fwd(float* g_ts, float* acts, int B, int n, int L, void* stream);
+/* dg[:n] = dacts·s·(1−t²), dg[n:] = dacts·t·s·(1−s) */
+int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, int L, void* stream);
+/* affine coupling (:173-178): xn[:, :h]=u[:, :h]; xn[:, h:] = exp(o[:, h:])·u[:, h:] + o[:, :h] */
+int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, void* stream);
+/* backward of the above given dxn and (added) d_logs; writes du (full 2h channels: du[:, :h]=dxn[:, :h]) and do */
+int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs,
+                     float* du, float* d_o, int B, int h, int L, void* stream);
+/* inverse coupling (:193-196): xn[:, h:] = (x[:, h:] − o[:, :h]) / exp(o[:, h:]) */
+int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, void* stream);
+int fst_coupling_inv_bwd(const float* xn, const float* o, const float* dxn,
+                         float* dx, float* d_o, int B, int h, int L, void* stream);
+
+/* generic fp32 elementwise helpers on contiguous buffers */
+int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */
+int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,
+                   int B, int C, int L, void* stream);                                  /* dst = a + b (b may be null) */
+
+/* ---------------------------------------------------------------------------------------------
+ * CPC InfoNCE (Comparison/SLARDA/train.py:72-76): for every prediction step i,
+ * total_i = enc_i·pred_iᵀ (B×B, K=C); nce_sum = Σ_i Σ_b log_softmax(total_i)[b,b]  (the caller
+ * multiplies by −1/(B·T)).  enc element (i,b,c) is read in place at enc[i*s_i + b*s_b + c*s_c]
+ * (a strided view of the [B,C,L] feature tensor); pred is [T,B,C] contiguous; lse [T,B] is kept
+ * for backward.  gout is the DEVICE scalar d loss / d nce.
+ * ------------------------------------------------------------------------------------------- */
+int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const float* pred,
+                    int T, int B, int C, float* lse, float* nce_sum /* scalar, zeroed */, void* stream);
+int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const float* pred, const float* lse,
+                    int T, int B, int C, const float* gout, float* denc /* same strides as enc */,
+                    float* dpred, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FST_HIP_H */

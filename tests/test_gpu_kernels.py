@@ -1,0 +1,268 @@
+"""HIP kernels vs plain torch references (fp64 on the CPU), through the C ABI.  Needs an MI355X.
+
+Tolerances: the f32 MFMA is an exact fp32 FMA chain, so conv results match an fp64 reference to
+~1e-6 relative to the operand scale; we assert 2e-5·scale (forward/data-grad) and 1e-4·scale for
+weight gradients (fp32 atomics across (b,t) splits, sums of B·L terms).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from feature_level_style_transfer_for_tsc_amd import ops
+from feature_level_style_transfer_for_tsc_amd.structure import generate_layer_parameter_list, out_channels, row_live_ranges
+
+DEV = "cuda"
+
+
+def ref_conv(x, w, bias, dil, pad_left, ntaps):
+    halo = (ntaps - 1) * dil
+    xp = F.pad(x.double(), (pad_left, halo - pad_left))
+    return F.conv1d(xp, w.double(), None if bias is None else bias.double(), dilation=dil)
+
+
+def assert_close(got, want, tol, what=""):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    scale = max(1e-6, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+CASES = [  # M, C0, ntaps, dil, pad_left, C1, B, L
+    (8, 6, 1, 1, 0, 0, 3, 40),
+    (50, 50, 1, 1, 0, 0, 4, 512),
+    (120, 25, 1, 1, 0, 0, 2, 150),
+    (50, 120, 1, 1, 0, 0, 2, 300),
+    (240, 120, 3, 1, 1, 25, 2, 200),
+    (240, 120, 3, 8, 8, 25, 2, 300),
+    (240, 120, 3, 128, 128, 25, 2, 512),
+    (16, 8, 3, 4, 4, 3, 3, 70),
+    (300, 33, 2, 1, 0, 0, 2, 129),
+]
+
+
+@pytest.mark.parametrize("M,C0,ntaps,dil,pad_left,C1,B,L", CASES)
+def test_conv_forward_backward(M, C0, ntaps, dil, pad_left, C1, B, L):
+    g = torch.Generator().manual_seed(M + 7 * C0 + L)
+    spec = ops.ConvSpec(M, C0, ntaps, dil, pad_left, C1=C1)
+    x0 = torch.randn(B, C0, L, generator=g, dtype=torch.float64, requires_grad=True)
+    w0 = (torch.randn(M, C0, ntaps, generator=g, dtype=torch.float64) / (C0 * ntaps) ** 0.5).requires_grad_(True)
+    bias = torch.randn(M, generator=g, dtype=torch.float64, requires_grad=True)
+    want = ref_conv(x0, w0, bias, dil, pad_left, ntaps)
+    x1 = w1 = None
+    if C1:
+        x1 = torch.randn(B, C1, L, generator=g, dtype=torch.float64, requires_grad=True)
+        w1 = (torch.randn(M, C1, 1, generator=g, dtype=torch.float64) / C1 ** 0.5).requires_grad_(True)
+        want = want + ref_conv(x1, w1, None, 1, 0, 1)
+    dy = torch.randn(B, M, L, generator=g, dtype=torch.float64)
+    (want * dy).sum().backward()
+
+    f = lambda t: None if t is None else t.detach().float().to(DEV)
+    y = spec.forward(f(x0), f(x1), f(w0), f(w1), f(bias))
+    assert_close(y, want, 2e-5, "forward")
+    dx0 = spec.grad_x0(f(dy), f(w0))
+    assert_close(dx0, x0.grad, 2e-5, "dx0")
+    if C1:
+        assert_close(spec.grad_x1(f(dy), f(w1)), x1.grad, 2e-5, "dx1")
+    dw0, dw1 = spec.grad_w(f(x0), f(x1), f(dy))
+    assert_close(dw0, w0.grad, 1e-4, "dw0")
+    if C1:
+        assert_close(dw1, w1.grad, 1e-4, "dw1")
+    assert_close(ops.row_sum(f(dy)), bias.grad, 1e-4, "dbias")
+
+
+def test_conv_epilogues_split_residual_accumulate():
+    g = torch.Generator().manual_seed(1)
+    B, L, n = 2, 100, 24
+    spec = ops.ConvSpec(2 * n, n)
+    x, w, b = torch.randn(B, n, L, generator=g), torch.randn(2 * n, n, 1, generator=g) / n ** 0.5, torch.randn(2 * n, generator=g)
+    a, out0 = torch.randn(B, n, L, generator=g), torch.randn(B, n, L, generator=g)
+    rs = ref_conv(x, w, b, 1, 0, 1)
+    a_next = torch.empty(B, n, L, device=DEV)
+    out = out0.to(DEV).clone()
+    spec.forward(x.to(DEV), None, w.to(DEV), None, b.to(DEV), y=a_next, res=a.to(DEV), y2=out, msplit=n, flags=ops.EPI_ACC2)
+    assert_close(a_next, a.double() + rs[:, :n], 2e-5, "residual half")
+    assert_close(out, out0.double() + rs[:, n:], 2e-5, "accumulated half")
+    # channel-slice views (explicit batch stride) as input and ACC1 output
+    wide = torch.randn(B, 2 * n, L, generator=g).to(DEV)
+    spec2 = ops.ConvSpec(n, n)
+    w2 = torch.randn(n, n, 1, generator=g) / n ** 0.5
+    acc = torch.ones(B, 2 * n, L, device=DEV)
+    ops.conv_gemm(spec2.fwd_plan(1), ops.pack_weights(spec2.fwd_plan(1), n, w2.to(DEV), spec2.s_w0()), wide[:, n:], None,
+                  None, B, L, n, acc[:, :n], nb=1, flags=ops.EPI_ACC1)
+    assert_close(acc[:, :n], 1.0 + ref_conv(wide[:, n:].cpu(), w2, None, 1, 0, 1), 2e-5, "view in / ACC1 out")
+    assert float((acc[:, n:] - 1).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("which", ["L0", "L1", "L2", "CLF0", "small"])
+def test_omni_scale_layers(which):
+    """The metric config's omni-scale layers (L=512, C_in=1): masked-tap skipping forward / data-grad, and
+    DENSE weight gradients (quirk Q1)."""
+    if which == "small":
+        lp = generate_layer_parameter_list(1, 13, [41 * 3, 41 * 12 * 2], 2)
+        layer, B, L = lp[1], 3, 77
+    else:
+        lp = generate_layer_parameter_list(1, 89, [1024, 229376], 1)
+        layer = {"L0": lp[0], "L1": lp[1], "L2": lp[2], "CLF0": [(50, o, k) for (_, o, k) in lp[0]]}[which]
+        B, L = 2, 512
+    C0, kmax, M = layer[0][0], layer[-1][2], out_channels(layer)
+    live = row_live_ranges(layer)
+    g = torch.Generator().manual_seed(len(layer) + M)
+    mask = torch.zeros(M, C0, kmax, dtype=torch.float64)
+    for m, (lo, hi) in enumerate(live):
+        mask[m, :, lo:hi] = 1
+    w_raw = torch.randn(M, C0, kmax, generator=g, dtype=torch.float64) / (C0 * 3) ** 0.5
+    w = (w_raw * mask).requires_grad_(True)
+    x = torch.randn(B, C0, L, generator=g, dtype=torch.float64, requires_grad=True)
+    bias = torch.randn(M, generator=g, dtype=torch.float64)
+    pl = int((kmax - 1) / 2)
+    want = ref_conv(x, w, bias, 1, pl, kmax)
+    dy = torch.randn(B, M, L, generator=g, dtype=torch.float64)
+    (want * dy).sum().backward()
+    spec = ops.ConvSpec(M, C0, kmax, 1, pl, row_live=live, dense_dw=True)
+    wd = w_raw.float().to(DEV)
+    lo_t = torch.tensor([r[0] for r in live], dtype=torch.int32, device=DEV)
+    hi_t = torch.tensor([r[1] for r in live], dtype=torch.int32, device=DEV)
+    ops.mask_taps_(wd, lo_t, hi_t)
+    assert_close(wd, w, 1e-7, "mask_taps")
+    f = lambda t: t.detach().float().to(DEV)
+    assert_close(spec.forward(f(x), None, wd, None, f(bias)), want, 2e-5, "omni forward")
+    assert_close(spec.grad_x0(f(dy), wd), x.grad, 2e-5, "omni dx")
+    dw, _ = spec.grad_w(f(x), None, f(dy))
+    assert_close(dw, w.grad, 1e-4, "omni dense dW")               # w.grad is dense: masked taps included
+    live_spec = ops.ConvSpec(M, C0, kmax, 1, pl, row_live=live, dense_dw=False)
+    dw_live, _ = live_spec.grad_w(f(x), None, f(dy))
+    assert_close(dw_live, w.grad * mask, 1e-4, "omni live-only dW")
+
+
+@pytest.mark.parametrize("training,relu", [(True, True), (True, False), (False, True)])
+def test_batch_norm(training, relu):
+    g = torch.Generator().manual_seed(3)
+    B, C, L = 5, 13, 70
+    y = (torch.randn(B, C, L, generator=g, dtype=torch.float64) * 2 + 0.7).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64, requires_grad=True)
+    rm, rv = torch.randn(C, generator=g, dtype=torch.float64), torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    out = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, training, 0.1, 1e-5)
+    out = F.relu(out) if relu else out
+    dout = torch.randn(B, C, L, generator=g, dtype=torch.float64)
+    (out * dout).sum().backward()
+    f = lambda t: t.detach().float().to(DEV)
+    yd, gd, bd = f(y).requires_grad_(True), f(gamma).requires_grad_(True), f(beta).requires_grad_(True)
+    rmd, rvd = f(rm), f(rv)
+    got = ops.BNActFn.apply(yd, gd, bd, rmd, rvd, training, relu, 1e-5, 0.1)
+    (got * f(dout)).sum().backward()
+    assert_close(got, out, 1e-5, "bn out")
+    assert_close(yd.grad, y.grad, 5e-5, "bn dx")
+    assert_close(gd.grad, gamma.grad, 5e-5, "bn dgamma")
+    assert_close(bd.grad, beta.grad, 5e-5, "bn dbeta")
+    assert_close(rmd, rm_ref, 1e-5, "running mean")
+    assert_close(rvd, rv_ref, 1e-5, "running var")
+
+
+def test_bn_add_bn_relu():
+    g = torch.Generator().manual_seed(4)
+    B, C, L = 4, 9, 50
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    ya, yb = mk(B, C, L).requires_grad_(True), (mk(B, C, L) * 3 - 1).requires_grad_(True)
+    ga, ba, gb, bb = [mk(C).requires_grad_(True) for _ in range(4)]
+    rma, rva, rmb, rvb = torch.zeros(C).double(), torch.ones(C).double(), torch.zeros(C).double(), torch.ones(C).double()
+    out = F.relu(F.batch_norm(ya, rma, rva, ga, ba, True, 0.1, 1e-5) + F.batch_norm(yb, rmb, rvb, gb, bb, True, 0.1, 1e-5))
+    dout = mk(B, C, L)
+    (out * dout).sum().backward()
+    f = lambda t: t.detach().float().to(DEV)
+    d = [f(t).requires_grad_(True) for t in (ya, ga, ba, yb, gb, bb)]
+    bufs = [torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(C, device=DEV), torch.ones(C, device=DEV)]
+    got = ops.BNAddBNReluFn.apply(d[0], d[1], d[2], bufs[0], bufs[1], d[3], d[4], d[5], bufs[2], bufs[3], True, 1e-5, 0.1)
+    (got * f(dout)).sum().backward()
+    assert_close(got, out, 1e-5, "out")
+    for t, r, name in zip(d, (ya, ga, ba, yb, gb, bb), ("dya", "dga", "dba", "dyb", "dgb", "dbb")):
+        assert_close(t.grad, r.grad, 5e-5, name)
+    assert_close(bufs[0], rma, 1e-5); assert_close(bufs[3], rvb, 1e-5)
+
+
+def test_gate_and_coupling():
+    lib_ops = ops
+    g = torch.Generator().manual_seed(5)
+    B, n, L = 3, 10, 33
+    gg = torch.randn(B, 2 * n, L, generator=g, dtype=torch.float64, requires_grad=True)
+    acts = torch.tanh(gg[:, :n]) * torch.sigmoid(gg[:, n:])
+    dacts = torch.randn(B, n, L, generator=g, dtype=torch.float64)
+    (acts * dacts).sum().backward()
+    from feature_level_style_transfer_for_tsc_amd import _lib
+    lib = _lib.load()
+    gd = gg.detach().float().to(DEV).clone()
+    ad = torch.empty(B, n, L, device=DEV)
+    _lib.check(lib.fst_gate_fwd(gd.data_ptr(), ad.data_ptr(), B, n, L, _lib.stream_ptr()), "gate_fwd")
+    assert_close(ad, acts, 1e-5, "gate acts")
+    dg = torch.empty(B, 2 * n, L, device=DEV)
+    _lib.check(lib.fst_gate_bwd(gd.data_ptr(), dacts.float().to(DEV).data_ptr(), dg.data_ptr(), B, n, L, _lib.stream_ptr()), "gate_bwd")
+    assert_close(dg, gg.grad, 1e-5, "gate grad")
+
+    h = 7
+    u = torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64, requires_grad=True)
+    o = (torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    xn = torch.cat([u[:, :h], torch.exp(o[:, h:]) * u[:, h:] + o[:, :h]], 1)
+    r = torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64)
+    ((xn * r).sum() + o[:, h:].sum() * 0.5).backward()
+    ud, od = u.detach().float().to(DEV).requires_grad_(True), o.detach().float().to(DEV).requires_grad_(True)
+    xnd = ops.CouplingFn.apply(ud, od)
+    ((xnd * r.float().to(DEV)).sum() + od[:, h:].sum() * 0.5).backward()
+    assert_close(xnd, xn, 1e-5, "coupling fwd"); assert_close(ud.grad, u.grad, 1e-5, "du"); assert_close(od.grad, o.grad, 1e-5, "do")
+
+    x = torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64, requires_grad=True)
+    o2 = (torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    xi = torch.cat([x[:, :h], (x[:, h:] - o2[:, :h]) / torch.exp(o2[:, h:])], 1)
+    (xi * r).sum().backward()
+    xd, o2d = x.detach().float().to(DEV).requires_grad_(True), o2.detach().float().to(DEV).requires_grad_(True)
+    xid = ops.CouplingInvFn.apply(xd, o2d)
+    (xid * r.float().to(DEV)).sum().backward()
+    assert_close(xid, xi, 1e-5, "inv fwd"); assert_close(xd.grad, x.grad, 1e-5, "inv dx"); assert_close(o2d.grad, o2.grad, 1e-5, "inv do")
+
+
+@pytest.mark.parametrize("B,C,L,T,t0", [(4, 6, 20, 10, 3), (37, 50, 128, 64, 9), (256, 50, 512, 256, 101)])
+def test_cpc_nce(B, C, L, T, t0):
+    g = torch.Generator().manual_seed(B + C)
+    feat = torch.randn(B, C, L, generator=g, dtype=torch.float64, requires_grad=True)
+    pred = (torch.randn(T, B, C, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    enc = feat[:, :, t0:t0 + T].permute(2, 0, 1)                  # [T, B, C]
+    total = torch.bmm(enc, pred.transpose(1, 2))
+    nce = -torch.diagonal(F.log_softmax(total, dim=-1), dim1=1, dim2=2).sum() / (B * T)
+    (nce * 1.7).backward()
+    fd, pd = feat.detach().float().to(DEV).requires_grad_(True), pred.detach().float().to(DEV).requires_grad_(True)
+    got = ops.CPCNceFn.apply(fd, pd, t0, T)
+    (got * 1.7).backward()
+    assert abs(got.item() - nce.item()) <= 2e-5 * max(1.0, abs(nce.item()))
+    assert_close(fd.grad, feat.grad, 5e-5, "dfeat"); assert_close(pd.grad, pred.grad, 5e-5, "dpred")
+
+
+def test_fixed_matmul():
+    g = torch.Generator().manual_seed(9)
+    Bx, D, O = 7, 640, 64
+    x = torch.randn(Bx, D, generator=g, dtype=torch.float64, requires_grad=True)
+    R = torch.randn(D, O, generator=g, dtype=torch.float64)
+    y = x @ R
+    dy = torch.randn(Bx, O, generator=g, dtype=torch.float64)
+    (y * dy).sum().backward()
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    Rd = R.float().to(DEV)
+    got = ops.FixedMatmulFn.apply(xd, Rd, Rd.t().contiguous())
+    (got * dy.float().to(DEV)).sum().backward()
+    assert_close(got, y, 2e-5, "x@R"); assert_close(xd.grad, x.grad, 2e-5, "dx")
+
+
+def test_argument_errors_are_reported_not_launched():
+    spec = ops.ConvSpec(8, 4)
+    x = torch.randn(2, 4, 16, device=DEV)
+    w = torch.randn(8, 4, 1, device=DEV)
+    plan = spec.fwd_plan(1)
+    a = ops.pack_weights(plan, 8, w, spec.s_w0())
+    with pytest.raises(RuntimeError, match="msplit"):
+        ops.conv_gemm(plan, a, x, None, None, 2, 16, 8, torch.empty(2, 8, 16, device=DEV), msplit=9)
+    with pytest.raises(RuntimeError, match="M="):
+        ops.conv_gemm(plan, a, x, None, None, 2, 16, 999, torch.empty(2, 8, 16, device=DEV))
+    with pytest.raises(ValueError):
+        ops.conv_gemm(plan, a, x.transpose(1, 2), None, None, 2, 16, 8, torch.empty(2, 8, 16, device=DEV))

@@ -1,0 +1,287 @@
+"""Drop-in modules on the MI355X vs (1) the committed golden fixtures produced by the reference itself and
+(2) the CPU oracle on fresh seeded inputs, incl. full-size property checks.  Needs an MI355X.
+
+Tolerances (fp32): values 1e-4 rel (north_star: logits/loss within 1e-4 rel); gradients 1e-3 of the
+module's gradient scale (sum-order differences; fp32 atomics in the weight-gradient reduction).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import feature_level_style_transfer_for_tsc_amd as fst
+from feature_level_style_transfer_for_tsc_amd import ops
+from oracle import restatement as R
+
+DEV = "cuda"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def tsd(d):
+    return {k: torch.tensor(v) for k, v in d.items()}
+
+
+def close(got, want, tol=1e-4, what="", scale=None):
+    got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float64)
+    want = want.detach().double().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float64)
+    s = scale if scale is not None else max(1e-6, float(np.abs(want).max()))
+    err = float(np.abs(got - want).max())
+    assert err <= tol * s, f"{what}: max err {err:.3e}, scale {s:.3e}, tol {tol}"
+
+
+def check_grads(module, want, tol=1e-3, what=""):
+    scale = max(float(np.abs(v).max()) for v in want.values())
+    named = dict(module.named_parameters())
+    for k, v in want.items():
+        assert named[k].grad is not None, f"{what}{k}: no grad"
+        close(named[k].grad, v, tol, f"{what}grad {k}", scale=scale)
+
+
+def spec_of(g):
+    return [[tuple(t) for t in l] for l in json.loads(str(g["spec"]))]
+
+
+# ------------------------------------------------------------------ golden fixtures (reference outputs)
+def test_feature_extractor_golden():
+    g = load("fe_small")
+    fe = fst.OS_CNN_res(spec_of(g)).to(DEV)
+    fe.load_state_dict(tsd(sub(g, "sd.")))
+    fe.train()
+    x = torch.tensor(g["x"], device=DEV, requires_grad=True)
+    y = fe(x)
+    close(y, g["y"], 1e-4, "fe forward")
+    (y * torch.tensor(g["r"], device=DEV)).sum().backward()
+    close(x.grad, g["dx"], 1e-3, "fe dx")
+    check_grads(fe, sub(g, "grad."), 1e-3, "fe ")                  # dense masked-tap dW included (Q1)
+    for k, v in sub(g, "sd_after.").items():
+        close(fe.state_dict()[k], v, 1e-4, "fe state after " + k)
+    fe.eval()
+    close(fe(x.detach()), load("fe_small_eval")["y_eval"], 1e-4, "fe eval")
+
+
+def test_feature_extractor_metric_spec_golden():
+    g = load("fe_metric_fwd")
+    spec, _ = fst.specs_for(512, 1)
+    fe = fst.OS_CNN_res(spec).to(DEV)
+    fe.load_state_dict(tsd(sub(g, "sd.")))
+    fe.train()
+    close(fe(torch.tensor(g["x"], device=DEV)), g["y"], 1e-4, "fe L=512 forward")
+
+
+def test_classifier_golden():
+    g = load("clf_small")
+    clf = fst.OS_CNN(spec_of(g), 3).to(DEV)
+    clf.load_state_dict(tsd(sub(g, "sd.")))
+    clf.train()
+    x = torch.tensor(g["x"], device=DEV, requires_grad=True)
+    logits, pooled = clf(x)
+    close(logits, g["logits"], 1e-4, "logits"); close(pooled, g["pooled"], 1e-4, "pooled")
+    ((logits * torch.tensor(g["rl"], device=DEV)).sum() + (pooled * torch.tensor(g["rp"], device=DEV)).sum()).backward()
+    close(x.grad, g["dx"], 1e-3, "clf dx")
+    check_grads(clf, sub(g, "grad."), 1e-3, "clf ")
+    clf.eval()
+    le, pe = clf(x.detach())
+    close(le, g["logits_eval"], 1e-4, "eval logits"); close(pe, g["pooled_eval"], 1e-4, "eval pooled")
+
+
+def test_waveglow_golden():
+    g = load("waveglow_small")
+    wg = fst.WaveGlow(3, 6, 8).to(DEV)
+    wg.load_state_dict(tsd(sub(g, "sd.")))
+    x = torch.tensor(g["x"], device=DEV, requires_grad=True)
+    out = wg(x)
+    close(out[0], g["z"], 1e-4, "z")
+    close(torch.stack(out[1]), g["log_s"], 1e-4, "log_s")
+    loss = fst.WaveGlowLoss()(out)
+    close(loss, g["loss"], 1e-4, "nf loss")
+    loss.backward()
+    close(x.grad, g["dx"], 1e-3, "wg dx")
+    check_grads(wg, sub(g, "grad."), 1e-3, "wg ")
+    wg.zero_grad()
+    zin = torch.tensor(g["zin"], device=DEV, requires_grad=True)
+    xi = wg.infer(zin)
+    close(xi, g["xi"], 1e-4, "infer")
+    (xi * torch.tensor(g["ri"], device=DEV)).sum().backward()
+    close(zin.grad, g["dzin"], 1e-3, "infer dz")
+    check_grads(wg, sub(g, "igrad."), 1e-3, "wg infer ")
+    assert all(c.conv.weight.grad is None for c in wg.convinv)     # Q2: cached inverse carries no gradient
+    wg.load_state_dict(tsd(sub(g, "sd_perturbed.")))               # Q2: the stale inverse is reused
+    close(wg.infer(zin.detach()), g["xi2"], 1e-4, "infer with stale inverse")
+
+
+def test_cpc_golden():
+    g = load("cpc_small")
+    cpc = fst.CPC(6, 8, 10).to(DEV)
+    cpc.load_state_dict(tsd(sub(g, "sd.")))
+    f = torch.tensor(g["feat"], device=DEV, requires_grad=True)
+    nce = cpc(f, int(g["t_samples"]))
+    close(nce, g["nce"], 1e-4, "nce")
+    nce.backward()
+    close(f.grad, g["dfeat"], 1e-3, "cpc dfeat")
+    check_grads(cpc, sub(g, "grad."), 1e-3, "cpc ")
+    torch.manual_seed(150)                                         # same global-RNG draw as the reference (Q6)
+    close(cpc(f.detach()), g["nce"], 1e-4, "nce with drawn t")
+
+
+def test_cdan_golden():
+    g = load("cdan_small")
+    ad = fst.AdversarialNetworkforCDAN(32, 16).to(DEV)
+    ad.load_state_dict(tsd(sub(g, "sd.")))
+    ad.dropout1.p = ad.dropout2.p = 0.0
+    ad.train()
+    rl = fst.RandomLayer([5 * 12, 3], output_dim=32)
+    rl.random_matrix = [torch.tensor(g["m0"]), torch.tensor(g["m1"])]
+    rl = rl.to(DEV)
+    ts = [torch.tensor(g[k], device=DEV, requires_grad=True) for k in ("ft", "fg", "lt", "lg")]
+    for i in range(3):
+        for t in ts:
+            t.grad = None
+        ad.zero_grad()
+        v = fst.CDAN(*ts, ad, rl)
+        close(v, g["vals"][i], 1e-4, f"cdan call {i}")
+        assert abs(ad.coeff - g["coeffs"][i]) < 1e-12
+    v.backward()
+    for t, k in zip(ts, ("dft", "dfg", "dlt", "dlg")):
+        close(t.grad, g[k], 1e-3, k)
+    check_grads(ad, sub(g, "grad."), 1e-3, "ad ")
+
+
+def test_small_heads_golden():
+    g = load("heads_small")
+    nt = fst.NoiseTransfer(6, 10).to(DEV)
+    nt.load_state_dict(tsd(sub(g, "sd.noise.")))
+    d = lambda k: torch.tensor(g[k], device=DEV)
+    close(nt(d("zt1"), d("zs1")), g["n1"], 1e-4, "noise 1")
+    zs2 = d("zs2").requires_grad_(True)
+    n2 = nt(d("zt2"), zs2)
+    close(n2, g["n2"], 1e-4, "noise 2 (Q5)")
+    (n2 * d("rn")).sum().backward()
+    close(zs2.grad, g["dzs2"], 1e-3)
+    check_grads(nt, sub(g, "grad.noise."), 1e-3, "noise ")
+    du = fst.DimensionUnification(4, 6, 14, 10).to(DEV)
+    du.load_state_dict(tsd(sub(g, "sd.dimunif.")))
+    close(du(d("xs")), g["du_out"], 1e-4, "dimunif")
+
+
+def _joint_trainer(g):
+    meta = json.loads(str(g["meta"]))
+    tup = lambda lp: [[tuple(t) for t in l] for l in lp]
+    cfg = fst.JointConfig(L_t=meta["L_t"], C_in_t=meta["C_in_t"], L_s=meta["L_s"], C_in_s=meta["C_in_s"],
+                          n_class_t=meta["ncls_t"], n_class_s=meta["ncls_s"], nf_channels=meta["nf"][2],
+                          cpc_hidden=meta["cpc"][1], cdan_dim=64, ad_hidden=32, dropout_p=0.0)
+    tr = fst.JointTrainer(cfg, DEV, fe_t_spec=tup(meta["lp_t"]), clf_spec=tup(meta["lp_clf"]), fe_s_spec=tup(meta["lp_s"]))
+    tr.load_params({name: tsd(sub(g, f"sd0.{name}.")) for name in tr.MODULES}, [torch.tensor(g["m0"]), torch.tensor(g["m1"])])
+    return tr
+
+
+def test_joint_step_golden():
+    """First joint step from the reference's captured state: all nine losses, GradNorm norms and weights,
+    and the accumulated gradients the reference's double backward leaves behind (Q3)."""
+    g = load("joint_small")
+    tr = _joint_trainer(g)
+    args = [torch.tensor(g[f"s0.{k}"], device=DEV) for k in ("x_t", "y_t", "x_s", "y_s")]
+    ts = tuple(int(v) for v in g["s0.t_samples"])
+    grads = {}
+
+    def capture():                                                 # grads right before the optimisers consume them
+        for name in tr.MODULES:
+            grads[name] = {n: p.grad.detach().clone() for n, p in tr.m[name].named_parameters() if p.grad is not None}
+    tr.on_grads_ready = capture
+    rep = tr.step(*args, epoch=0, t_samples=ts)
+    for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s"):
+        want = float(g[f"s0.loss.{k}"])
+        assert abs(rep[k].item() - want) <= 1e-4 * max(1.0, abs(want)), (k, rep[k].item(), want)
+    close(rep["logit_t"], g["s0.logit_t"], 1e-4, "logit_t")
+    close(rep["logit_s2t"], g["s0.logit_s2t"], 1e-4, "logit_s2t")
+    close(rep["feat_s2t"], g["s0.feat_s2t"], 1e-4, "feat_s2t")
+    close(rep["norms_t"], g["s0.norms_t"], 1e-3, "GradNorm norms_t")
+    close(rep["norms_s"], g["s0.norms_s"], 1e-3, "GradNorm norms_s")
+    close(rep["w_t"], g["s0.w_t"], 1e-4, "w_t"); close(rep["w_s"], g["s0.w_s"], 1e-4, "w_s")
+    for name in tr.MODULES:
+        want = sub(g, f"s0.grad.{name}.")
+        scale = max(float(np.abs(v).max()) for v in want.values())
+        for k, v in want.items():
+            close(grads[name][k], v, 2e-3, f"Q3 grad {name}.{k}", scale=scale)
+
+
+# ------------------------------------------------------------------ oracle on fresh inputs, metric shapes
+def test_waveglow_metric_width_vs_oracle():
+    """WaveGlow(3, 50, 120) — the real widths — forward loss, backward and infer vs the CPU oracle (B=2, L=512)."""
+    gen = torch.Generator().manual_seed(21)
+    P = R.init_waveglow(3, 50, 120, gen, zero_end=False)
+    wg = fst.WaveGlow(3, 50, 120).to(DEV)
+    wg.load_state_dict({k: v.detach() for k, v in P.items()})
+    x = torch.randn(2, 50, 512, generator=gen)
+    xo = x.clone().requires_grad_(True)
+    out_o = R.waveglow_forward(xo, P, 3)
+    loss_o = R.waveglow_loss(out_o)
+    loss_o.backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = wg(xd)
+    loss = fst.WaveGlowLoss()(out)
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    close(out[0], out_o[0], 1e-4, "z")
+    close(xd.grad, xo.grad, 1e-3, "dx")
+    check_grads(wg, {k: v.grad.numpy() for k, v in P.items() if v.grad is not None}, 1e-3, "wg120 ")
+    z = torch.randn(2, 50, 512, generator=gen)
+    close(wg.infer(z.to(DEV)), R.waveglow_infer(z, P, 3, {}), 1e-4, "infer")
+
+
+def test_metric_shape_classifier_step_vs_oracle():
+    """S1 at the metric spec (L=512, C_in=1), B=8: loss, logits and post-step weights vs the oracle."""
+    gen = torch.Generator().manual_seed(33)
+    fe_spec, clf_spec = R.train_specs(512, 1)
+    Pf, Pc = R.init_feature_extractor(fe_spec, gen), R.init_classifier(clf_spec, 4, gen)
+    tr = fst.ClassifierTrainer(512, 1, 4, DEV)
+    tr.fe.load_state_dict({k: v.detach() for k, v in Pf.items()})
+    tr.clf.load_state_dict({k: v.detach() for k, v in Pc.items()})
+    x, y = torch.randn(8, 1, 512, generator=gen), torch.randint(4, (8,), generator=gen)
+    oracle = R.ClassifierStep(Pf, Pc, fe_spec, clf_spec)
+    loss_o, logits_o = oracle.step(x, y)
+    loss, logits = tr.step(x.to(DEV), y.to(DEV))
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    close(logits, logits_o, 1e-4, "logits")
+    close(tr.clf.hidden.weight, Pc["hidden.weight"], 1e-3, "hidden.weight after step")
+
+
+# ------------------------------------------------------------------ full-size properties (B=256, L=512)
+def test_full_size_flow_round_trip_and_bn_moments():
+    """At BASELINE's size no oracle is affordable; use properties: infer(forward(x)) = x when the cached
+    inverse is fresh, and train-mode BN output has zero mean / unit variance per channel."""
+    torch.manual_seed(0)
+    B, C, L = 256, 50, 512
+    wg = fst.WaveGlow(3, C, 120).to(DEV)
+    for wn in wg.WN:
+        wn.end.weight.data.normal_(0, 0.02); wn.end.bias.data.normal_(0, 0.02)
+    x = torch.randn(B, C, L, device=DEV)
+    with torch.no_grad():
+        z, log_s, log_det = wg(x)
+        back = wg.infer(z)
+    close(back, x, 1e-3, "flow round trip")
+    fe_spec, _ = fst.specs_for(L, 1)
+    fe = fst.OS_CNN_res(fe_spec).to(DEV)
+    fe.train()
+    layer = fe.net_1.net.layer_list[1]
+    h = fe.net_1.net.layer_list[0](torch.randn(B, 1, L, device=DEV))
+    y = layer.conv(h)
+    out = ops.BNActFn.apply(y, layer.bn.weight, layer.bn.bias, layer.bn.running_mean, layer.bn.running_var, True, False,
+                            1e-5, 0.1)
+    m, v = out.mean(dim=(0, 2)), out.var(dim=(0, 2), unbiased=False)
+    assert float(m.abs().max()) < 1e-4 and float((v - 1).abs().max()) < 1e-3
+    # linearity of the omni-scale conv in its input (bias removed)
+    y2 = layer.conv(2.5 * h)
+    b = layer.conv1d.bias.view(1, -1, 1)
+    close(y2 - b, 2.5 * (y - b), 1e-4, "conv linearity")
