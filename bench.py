@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train-step samples/sec of the full joint pipeline (BASELINE.json configs[1]:
+OS_CNN + Simplified_NF_WaveGlow + C_DAN (+CPC, GradNorm), synthetic univariate L=512, batch 256 per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of train_and_test.py:539-766 over one batch of 256 (target, source) pairs per GPU:
+forward of every module, the GradNorm partial backward passes, one full backward, all optimiser updates.
+Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_batch(B, C_in, L, n_class, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C_in, L, generator=g)
+    x = (x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True)             # z-normalised per series (UCR convention)
+    y = torch.randint(n_class, (B,), generator=g)
+    return x.to(device), y.to(device)
+
+
+def cpu_baseline(L: int, pairs: int, steps: int):
+    """The CPU oracle (oracle/restatement.py, a port of the reference's step) timed on this host's cores on a
+    bounded sample of the same workload.  Baseline only — never the product path."""
+    from oracle import restatement as R
+    torch.manual_seed(1234)
+    js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=1234)
+    g = torch.Generator().manual_seed(99)
+    mk = lambda: ((lambda x: (x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True))(torch.randn(pairs, 1, L, generator=g)),
+                  torch.randint(4, (pairs,), generator=g))
+    (x_t, y_t), (x_s, y_s) = mk(), mk()
+    js.step(x_t, y_t, x_s, y_s, epoch=0)                                      # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        js.step(x_t, y_t, x_s, y_s, epoch=0)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": pairs / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"joint step S2 (L={L}, C_in=1), {pairs} pairs/step (per-sample cost is batch-linear), "
+                      f"{steps} timed steps after 1 warm-up, autograd anomaly mode off, {dt:.2f} s/step"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--length", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    import torch.distributed as dist
+    bucket = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.barrier()
+    import feature_level_style_transfer_for_tsc_amd as fst
+    from feature_level_style_transfer_for_tsc_amd import ops
+    if world > 1:
+        bucket = fst.GradBucket()
+
+    torch.manual_seed(1234)                                                   # identical replicas on every rank
+    cfg = fst.JointConfig(L_t=args.length, C_in_t=1, L_s=args.length, C_in_s=1, n_class_t=4, n_class_s=4)
+    trainer = fst.JointTrainer(cfg, device, bucket)
+    x_t, y_t = synthetic_batch(args.batch, 1, args.length, 4, device, 1000 + rank)
+    x_s, y_s = synthetic_batch(args.batch, 1, args.length, 4, device, 2000 + rank)
+    T_half = (args.length // 2) // 2
+    torch.manual_seed(4321)                                                   # CPC start indices: same on every rank
+
+    def one_step(i):
+        t = (int(torch.randint(T_half, (1,))), int(torch.randint(T_half, (1,))))
+        return trainer.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=t)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer = ops.KernelTimer()
+    ops.KERNEL_TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        rep = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * args.batch * args.steps / dt
+
+    if rank == 0:
+        ks = timer.summary()
+        dom_key = max(ks, key=lambda k: ks[k]["total_ms"])
+        dom = ks[dom_key]
+        achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        conv_ms = sum(v["total_ms"] for v in ks.values()) / args.steps
+        roofline = {"bound": "mfma", "kernel": dom_key, "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches"] / args.steps,
+                    "conv_engine_ms_per_step": conv_ms,
+                    "kernels": {k: {"avg_us": round(v["avg_us"], 1), "launches_per_step": v["launches"] / args.steps,
+                                    "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2)} for k, v in ks.items()}}
+        line = {"metric": "train-step samples/sec (univariate TS, len=512, batch=256)", "value": value, "unit": "samples/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[1]: full joint step (OS_CNN_res x2 + OS_CNN x3 + WaveGlow(3,50,120) fwd x2 + infer "
+                                       "+ CPC x2 + CDAN + GradNorm + RMSprop/Adam), univariate L=%d, %d pairs/GPU" % (args.length, args.batch),
+                           "global_batch": world * args.batch, "seq_len": args.length, "parallelism": f"dp{world}"},
+                "losses": {k: float(rep[k]) for k in ("nf_t", "nf_s", "ce_t", "ce_s", "sl_t", "cdan")},
+                "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.length, args.cpu_pairs, 2)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

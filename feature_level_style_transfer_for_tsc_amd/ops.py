@@ -20,6 +20,50 @@ LDS_BUDGET = 96 * 1024
 _PARTIAL_BACKWARD = False
 
 
+class KernelTimer:
+    """HIP-event timing of the conv-engine launches on the launch stream (used by bench.py's roofline leg).
+    Keyed by the kernel template a launch dispatches to, so totals line up with rocprofv3's per-kernel stats."""
+
+    def __init__(self):
+        self.records = {}          # key -> list of (start_event, end_event, algorithmic_flops)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, key: str, start, flops: float):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.setdefault(key, []).append((start, ev, flops))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[key] = {"launches": len(recs), "total_ms": ms, "avg_us": 1e3 * ms / len(recs),
+                        "flops": sum(f for _, _, f in recs)}
+        return out
+
+
+KERNEL_TIMER: Optional[KernelTimer] = None
+
+
+def _plan_macs_per_step(plan: Plan, M: int) -> int:
+    """Algorithmic MACs per (batch, timestep) of a plan: valid rows × live taps × real channels."""
+    total = 0
+    ch, en = plan.chunks(), plan.entries()
+    rows_per_group = plan.MB * 32
+    for g in range(plan.n_mgroups):
+        rows = max(0, min(M, (g + 1) * rows_per_group) - g * rows_per_group)
+        for q in range(plan.n_chunks):
+            lo, hi = int(en[g, q, 0]), int(en[g, q, 1])
+            if hi > lo:
+                total += rows * (hi - lo) * int(ch[q, 2])
+    return total
+
+
 class partial_backward:
     """Context: a backward pass whose only wanted parameter gradients belong to convs flagged
     ``spec.always_weight_grad`` (GradNorm's shared OS_block); every other conv skips its weight-gradient kernels."""
@@ -84,9 +128,12 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
     y_bs = _ncl(y, "y")[0] if y is not None else 0
     res_bs = _ncl(res, "res")[0] if res is not None else 0
     y2_bs = _ncl(y2, "y2")[0] if y2 is not None else 0
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     check(lib.fst_conv_gemm(ptr(x0), x0_bs, ptr(x1), x1_bs, ptr(a), ptr(plan.dev(x0.device)), plan.host_ptr(),
                             plan.length, ptr(bias), ptr(y), y_bs, ptr(res), res_bs, ptr(y2), y2_bs, msplit, B, L, M,
                             nb, ksplit, flags, stream_ptr()), "fst_conv_gemm")
+    if t0 is not None:
+        KERNEL_TIMER.end(f"conv_gemm_kernel<{plan.MB}, {nb}>", t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
 
 
 def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor], msplit: int, B: int,
@@ -97,9 +144,12 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
     x1_bs = _ncl(x1, "x1")[0] if x1 is not None else 0
     dy_bs, _ = _ncl(dy, "dy")
     dy2_bs = _ncl(dy2, "dy2")[0] if dy2 is not None else 0
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     check(lib.fst_conv_wgrad(ptr(x0), x0_bs, ptr(x1), x1_bs, ptr(dy), dy_bs, ptr(dy2), dy2_bs, msplit, ptr(da),
                              ptr(plan.dev(x0.device)), plan.host_ptr(), plan.length, B, L, M, ksplit, stream_ptr()),
           "fst_conv_wgrad")
+    if t0 is not None:
+        KERNEL_TIMER.end(f"conv_wgrad_kernel<{plan.MB // 4}, 32>", t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
     return da
 
 
