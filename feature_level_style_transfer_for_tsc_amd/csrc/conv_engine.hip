@@ -168,6 +168,172 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient, software-pipelined variant.
+//
+// Requirements (checked on the host; plan.py builds such plans with chunk_c=16, split_taps=True):
+// every live (M-group, chunk) entry is a SINGLE tap of at most PIPE_C channels, i.e. one "stage" =
+// at most PIPE_C/2 k-steps.  Both operands of a stage go through LDS: the A records (packed weights,
+// MB·256 B per k-step, copied with 16-B loads) and the B tile [PIPE_C][TILE_N] of shifted input rows.
+// Stage s+1 is fetched global→registers while stage s is multiplied, then written to the other LDS
+// buffer: one barrier per stage, global latency hidden behind 64 MFMAs per wave, and at ≤ 48 KiB LDS
+// and < 256 VGPRs two workgroups share a CU so one's barrier is the other's MFMA time.
+// ------------------------------------------------------------------------------------------------
+#define PIPE_C 16
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TILE_N = 128 * NB;
+  constexpr int NREC = PIPE_C / 2;
+  constexpr int A_FLOATS = NREC * MB * 64;
+  constexpr int B_FLOATS = PIPE_C * TILE_N;
+  constexpr int AV = (A_FLOATS / 4 + 255) / 256;     // float4 per thread per stage
+  constexpr int BV = B_FLOATS / 256;                 // floats per thread per stage
+  constexpr int LOG_N = NB == 1 ? 7 : (NB == 2 ? 8 : 9);
+  const PlanView pv = plan_view(p.plan);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.tiles_per_seq;
+  const int t0 = (blockIdx.x - b * p.tiles_per_seq) * TILE_N;
+  const int g = blockIdx.y;
+  const int q_begin = (int)(((long long)blockIdx.z * pv.n_chunks) / p.ksplit);
+  const int q_end = (int)(((long long)(blockIdx.z + 1) * pv.n_chunks) / p.ksplit);
+  const int wave_n0 = wave * NB * 32;
+  const int L = p.L;
+  constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;      // buffer b: A at lds + b*STAGE_FLOATS, B right after it
+  const int32_t* ent = pv.mg + 4 * (g * pv.n_chunks);
+
+  auto next_live = [&](int q) {
+    while (q < q_end && ent[4 * q + 1] <= ent[4 * q]) ++q;
+    return q;
+  };
+
+  float4 a_st[AV];
+  float b_st[BV];
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jcol = tid & (TILE_N - 1);
+  auto fetch = [&](int q) {
+    const int32_t* c = pv.chunk + 4 * q;
+    const int32_t* e = ent + 4 * q;
+    const int c_count = c[2];
+    const int nvec = (((c_count + 1) & ~1) / 2) * MB * 16;
+    const float4* asrc = reinterpret_cast<const float4*>(p.a + (long long)e[2] * (MB * 64));
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int idx = tid + 256 * i;
+      a_st[i] = idx < nvec ? asrc[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float* xb = p.x[c[0]] + (long long)b * p.x_bs[c[0]] + (long long)c[1] * L;
+    const int tbase = t0 - pv.pad_left + e[0] * pv.dil;
+    // element el = tid + 256*i of the [PIPE_C][TILE_N] tile: row = (tid >> LOG_N) + (256 >> LOG_N)*i is
+    // wave-uniform, column j = tid & (TILE_N-1) is the only per-lane address part
+    const int row0 = wave_s >> (LOG_N - 6);
+    const bool t_ok = tbase + jcol >= 0 && tbase + jcol < L;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+      const int cc = row0 + (256 >> LOG_N) * i;
+      const float* rp = xb + ((long long)cc * L + tbase);
+      b_st[i] = (t_ok && cc < c_count) ? rp[jcol] : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < A_FLOATS / 4) reinterpret_cast<float4*>(lds + buf * STAGE_FLOATS)[idx] = a_st[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BV; ++i) lds[buf * STAGE_FLOATS + A_FLOATS + tid + 256 * i] = b_st[i];
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  int q = next_live(q_begin);
+  if (q < q_end) {
+    fetch(q);
+    commit(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  while (q < q_end) {
+    const int qn = next_live(q + 1);
+    if (qn < q_end) fetch(qn);
+    const int nrec = ((pv.chunk[4 * q + 2] + 1) & ~1) / 2;
+    const float* ap = lds + buf * STAGE_FLOATS + lane;
+    const float* bp = lds + buf * STAGE_FLOATS + A_FLOATS + half * TILE_N + wave_n0 + l31;
+    for (int r = 0; r < nrec; ++r) {
+      float av[MB], bv[NB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) av[mb] = ap[(r * MB + mb) * 64];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[2 * r * TILE_N + nb * 32];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+    }
+    if (qn < q_end) commit(buf ^ 1);
+    __syncthreads();
+    q = qn;
+    buf ^= 1;
+  }
+
+  const bool add_bias = p.bias != nullptr && blockIdx.z == 0;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (g * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= p.M) continue;
+      const float bias_v = add_bias ? p.bias[m] : 0.f;
+      float* dst;
+      const float* resp = nullptr;
+      bool accum;
+      if (m < p.msplit) {
+        dst = p.y + (long long)b * p.y_bs + (long long)m * L;
+        if (p.res) resp = p.res + (long long)b * p.res_bs + (long long)m * L;
+        accum = (p.flags & FST_EPI_ACC1) != 0;
+      } else {
+        dst = p.y2 + (long long)b * p.y2_bs + (long long)(m - p.msplit) * L;
+        accum = (p.flags & FST_EPI_ACC2) != 0;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int t = t0 + wave_n0 + nb * 32 + l31;
+        if (t >= L) continue;
+        float v = acc[mb][nb][r] + bias_v;
+        if (p.flags & FST_EPI_ATOMIC) {
+          atomicAdd(dst + t, v);
+        } else {
+          if (resp) v += resp[t];
+          if (accum) v += dst[t];
+          if (p.flags & FST_EPI_RELU) v = fmaxf(v, 0.f);
+          dst[t] = v;
+        }
+      }
+    }
+  }
+}
+
+static bool plan_is_pipeable(const PlanView& pv) {
+  for (int q = 0; q < pv.n_chunks; ++q) {
+    if (((pv.chunk[4 * q + 2] + 1) & ~1) > PIPE_C) return false;
+    for (int g = 0; g < pv.n_mgroups; ++g) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      if (e[1] > e[0] + 1) return false;
+    }
+  }
+  return true;
+}
+
 typedef void (*conv_gemm_fn)(ConvGemmParams);
 
 static conv_gemm_fn pick_conv_gemm(int MB, int NB) {
@@ -188,6 +354,24 @@ static conv_gemm_fn pick_conv_gemm(int MB, int NB) {
     switch (MB) {
       case 1: return conv_gemm_kernel<1, 4>;
       case 2: return conv_gemm_kernel<2, 4>;
+    }
+  }
+  return nullptr;
+}
+
+static conv_gemm_fn pick_conv_gemm_pipe(int MB, int NB) {
+  if (NB == 1) {
+    switch (MB) {
+      case 1: return conv_gemm_pipe_kernel<1, 1>;
+      case 2: return conv_gemm_pipe_kernel<2, 1>;
+      case 4: return conv_gemm_pipe_kernel<4, 1>;
+      case 8: return conv_gemm_pipe_kernel<8, 1>;
+    }
+  } else if (NB == 2) {
+    switch (MB) {
+      case 1: return conv_gemm_pipe_kernel<1, 2>;
+      case 2: return conv_gemm_pipe_kernel<2, 2>;
+      case 4: return conv_gemm_pipe_kernel<4, 2>;
     }
   }
   return nullptr;
@@ -233,7 +417,8 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   bool needs_x1 = false;
   for (int q = 0; q < pv.n_chunks; ++q) needs_x1 |= pv.chunk[4 * q] == 1;
   FST_REQUIRE(!needs_x1 || x1 != nullptr, "fst_conv_gemm: plan reads input 1 but x1 is null");
-  conv_gemm_fn fn = pick_conv_gemm(pv.MB, nb_cfg);
+  const bool pipe = plan_is_pipeable(pv) && pick_conv_gemm_pipe(pv.MB, nb_cfg) != nullptr;
+  conv_gemm_fn fn = pipe ? pick_conv_gemm_pipe(pv.MB, nb_cfg) : pick_conv_gemm(pv.MB, nb_cfg);
   FST_REQUIRE(fn != nullptr, "fst_conv_gemm: no kernel for MB=%d NB=%d", pv.MB, nb_cfg);
   const int TILE_N = 128 * nb_cfg;
 
@@ -264,7 +449,11 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   }
   FST_REQUIRE(max_w > 0, "fst_conv_gemm: plan has no live taps");
   p.ldw = max_w;
-  const size_t lds_bytes = (size_t)pv.chunk_cap * p.ldw * sizeof(float);
+  size_t lds_bytes = (size_t)pv.chunk_cap * p.ldw * sizeof(float);
+  if (pipe) {
+    p.mg_per_wg = 1;
+    lds_bytes = 2 * ((size_t)(PIPE_C / 2) * pv.MB * 64 + (size_t)PIPE_C * TILE_N) * sizeof(float);
+  }
   FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_conv_gemm: LDS window %zu B exceeds 160 KiB (chunk_cap=%d ldw=%d)",
               lds_bytes, pv.chunk_cap, p.ldw);
   if (lds_bytes > 48 * 1024) {
@@ -295,11 +484,19 @@ struct WgradParams {
 
 #define WG_ITEMS 4   // row-blocks (32 packed K-rows each) per workgroup
 
-template <int CB, int TW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+// CB: output-channel blocks per wave (M tile = 4*CB*32).  WIDE=false: every chunk is a single tap of ≤ 32
+// channels (window = TW columns, up to WG_ITEMS windows per workgroup); WIDE=true: one windowed chunk of
+// ≤ 64 channels and ≤ 128 columns (omni-scale layers, all items of a workgroup share it).
+// The next (b,t) tile is fetched global→registers while the current one is multiplied.
+template <int CB, int TW, bool WIDE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(TW == 32, "staging maps one half-wave to one 32-sample row");
   constexpr int MBW = 4 * CB;
   constexpr int DYS = TW + 1;   // odd row stride: lanes ↔ rows never share a bank
+  constexpr int DYV = MBW * 32 / 8;                      // dy floats per thread per tile
+  constexpr int NREG = WIDE ? 1 : WG_ITEMS;              // staged windows per workgroup
+  constexpr int XV = WIDE ? 32 : 4;                      // x floats per thread per window
   const PlanView pv = plan_view(p.plan);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -322,6 +519,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   }
   if (g < 0) return;
   const int m0 = g * MBW * 32;
+
+  // per staged window: source rows, channel count, first time sample relative to the tile
+  const float* reg_src[NREG];
+  int reg_cnt[NREG], reg_shift[NREG], reg_width[NREG];
+  long long reg_bs[NREG];
+#pragma unroll
+  for (int r = 0; r < NREG; ++r) { reg_src[r] = nullptr; reg_cnt[r] = 0; reg_shift[r] = 0; reg_width[r] = 0; reg_bs[r] = 0; }
+#pragma unroll
+  for (int i = 0; i < WG_ITEMS; ++i) {
+    if (i >= nit || (i > 0 && it_region[i] == it_region[i - 1])) continue;
+    const int32_t* c = pv.chunk + 4 * it_q[i];
+    const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + it_q[i]);
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if (r == it_region[i]) {
+        reg_src[r] = p.x[c[0]] + (long long)c[1] * L;
+        reg_bs[r] = p.x_bs[c[0]];
+        reg_cnt[r] = c[2];
+        reg_shift[r] = e[0] * dil - pv.pad_left;
+        reg_width[r] = (e[1] - 1 - e[0]) * dil + TW;
+      }
+    }
+  }
 
   // per-lane LDS row offset of each item's A-operand row (a packed K-row = (tap, channel))
   int rowoff[WG_ITEMS];
@@ -354,46 +574,88 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
   const int tile_begin = (int)(((long long)blockIdx.x * n_tiles) / p.ksplit);
   const int tile_end = (int)(((long long)(blockIdx.x + 1) * n_tiles) / p.ksplit);
 
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
+  float dy_st[DYV];
+  float x_st[NREG][XV];
+  // Addressing: the row part of every address is wave-uniform (SGPR arithmetic); one per-lane offset
+  // (half·L + l31, or lane) is the only address VGPR, so nothing large is hoisted out of the tile loop.
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vlane = half * L + l31;
+  auto fetch = [&](int tile) {
     const int b = tile / p.tiles_per_seq;
     const int tt0 = (tile - b * p.tiles_per_seq) * TW;
-    __syncthreads();   // previous tile's readers are done
-    // stage the X windows (one per distinct chunk among the items)
+    const bool t_ok = tt0 + l31 < L;
+    // dy tile: one half-wave per 32-sample row; rows m_even + half (msplit is even: a wave's two rows share a side)
 #pragma unroll
-    for (int i = 0; i < WG_ITEMS; ++i) {
-      if (i >= nit || (i > 0 && it_region[i] == it_region[i - 1])) continue;
-      const int q = it_q[i];
-      const int32_t* c = pv.chunk + 4 * q;
-      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
-      const int src = c[0], c_count = c[2], c_pad = (c[2] + 1) & ~1;
-      const int width = (e[1] - 1 - e[0]) * dil + TW;
-      const int tbase = tt0 - pv.pad_left + e[0] * dil;
-      const float* xb = p.x[src] + (long long)b * p.x_bs[src] + (long long)c[1] * L;
-      float* reg = xreg + it_region[i] * p.region_floats;
-      for (int cc = wave; cc < c_pad; cc += 4) {
-        const float* row = xb + (long long)cc * L;
-        const bool live = cc < c_count;
-        for (int j = lane; j < width; j += 64) {
-          const int t = tbase + j;
-          reg[cc * ldw + j] = (live && t >= 0 && t < L) ? row[t] : 0.f;
+    for (int i = 0; i < DYV; ++i) {
+      const int m_even = m0 + wave_s * 2 + 8 * i;
+      const float* rp = (m_even < p.msplit)
+                            ? p.dy + ((long long)b * p.dy_bs + (long long)m_even * L + tt0)
+                            : p.dy2 + ((long long)b * p.dy2_bs + (long long)(m_even - p.msplit) * L + tt0);
+      dy_st[i] = (t_ok && m_even + half < p.M) ? rp[vlane] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if (reg_src[r] == nullptr) continue;
+      const int tbase = tt0 + reg_shift[r];
+      if (WIDE) {
+        // rows cc = wave + 4*i (i < 16), columns lane and lane+64
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int cc = wave_s + 4 * i;
+          const float* rp = reg_src[r] + ((long long)b * reg_bs[r] + (long long)cc * L + tbase);
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int j = lane + 64 * k, t = tbase + j;
+            x_st[r][2 * i + k] = (cc < reg_cnt[r] && j < reg_width[r] && t >= 0 && t < L) ? rp[j] : 0.f;
+          }
+        }
+      } else {
+        // rows cc = wave*2 + half + 8*i (i < 4), column l31
+        const int t = tbase + l31;
+        const bool ok = t >= 0 && t < L;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cc_even = wave_s * 2 + 8 * i;
+          const float* rp = reg_src[r] + ((long long)b * reg_bs[r] + (long long)cc_even * L + tbase);
+          x_st[r][i] = (ok && cc_even + half < reg_cnt[r]) ? rp[vlane] : 0.f;
         }
       }
     }
-    // stage the dy tile [MBW*32][TW]
-    static_assert(TW == 32, "dy staging maps one half-wave to one 32-sample row");
-    for (int ml = wave * 2 + half; ml < MBW * 32; ml += 8) {
-      const int m = m0 + ml;
-      const float* row = nullptr;
-      if (m < p.M)
-        row = (m < p.msplit) ? p.dy + (long long)b * p.dy_bs + (long long)m * L
-                             : p.dy2 + (long long)b * p.dy2_bs + (long long)(m - p.msplit) * L;
-      const int t = tt0 + l31;
-      dyt[ml * DYS + l31] = (row != nullptr && t < L) ? row[t] : 0.f;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < DYV; ++i) dyt[(wave * 2 + half + 8 * i) * DYS + l31] = dy_st[i];
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      if (reg_src[r] == nullptr) continue;
+      float* reg = xreg + r * p.region_floats;
+      if (WIDE) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int cc = wave + 4 * i, j = lane + 64 * k;
+            if (cc < pv.chunk_cap && j < reg_width[r]) reg[cc * ldw + j] = x_st[r][2 * i + k];
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cc = wave * 2 + half + 8 * i;
+          if (cc < pv.chunk_cap) reg[cc * ldw + l31] = x_st[r][i];
+        }
+      }
     }
+  };
+
+  if (tile_begin < tile_end) fetch(tile_begin);
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    __syncthreads();   // previous tile's readers are done
+    commit();
     __syncthreads();
+    if (tile + 1 < tile_end) fetch(tile + 1);
 
     const float* bbase = dyt + (wave * CB * 32 + l31) * DYS + half;
-#pragma unroll 4
+#pragma unroll 1
     for (int tau = 0; tau < TW; tau += 2) {
       float av[WG_ITEMS], bv[CB];
 #pragma unroll
@@ -446,6 +708,7 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   FST_REQUIRE(pv.n_items > 0 && pv.items_per_wg == WG_ITEMS && pv.n_items % WG_ITEMS == 0,
               "fst_conv_wgrad: plan has no item table for %d items/workgroup", WG_ITEMS);
   FST_REQUIRE(msplit >= 0 && msplit <= M && (msplit == M || dy2 != nullptr), "fst_conv_wgrad: bad msplit=%d", msplit);
+  FST_REQUIRE(msplit == M || msplit % 2 == 0, "fst_conv_wgrad: a split dy needs an even msplit (got %d)", msplit);
   FST_REQUIRE(B > 0 && L > 0 && ksplit >= 1, "fst_conv_wgrad: bad sizes");
   bool needs_x1 = false;
   for (int q = 0; q < pv.n_chunks; ++q) needs_x1 |= pv.chunk[4 * q] == 1;
@@ -464,10 +727,15 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   const int n_tiles = B * p.tiles_per_seq;
   p.ksplit = ksplit < n_tiles ? ksplit : n_tiles;
   int max_w = 0;
+  bool wide = false;
   for (int q = 0; q < pv.n_chunks; ++q)
     for (int g = 0; g < pv.n_mgroups; ++g) {
       const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
-      if (e[1] > e[0]) { int w = (e[1] - 1 - e[0]) * pv.dil + TW; max_w = max_w > w ? max_w : w; }
+      if (e[1] > e[0]) {
+        int w = (e[1] - 1 - e[0]) * pv.dil + TW;
+        max_w = max_w > w ? max_w : w;
+        if (e[1] > e[0] + 1) wide = true;
+      }
     }
   FST_REQUIRE(max_w > 0, "fst_conv_wgrad: plan has no live taps");
   p.ldw = max_w | 1;                                     // odd stride: A-operand lanes walk channels
@@ -482,10 +750,19 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
     }
     p.n_regions = p.n_regions > distinct ? p.n_regions : distinct;
   }
+  if (wide) {
+    FST_REQUIRE(p.n_regions == 1 && pv.chunk_cap <= 64 && max_w <= 128,
+                "fst_conv_wgrad: windowed plan needs one chunk per workgroup, <= 64 channels, <= 128 columns "
+                "(regions=%d chunk_cap=%d width=%d)", p.n_regions, pv.chunk_cap, max_w);
+  } else {
+    FST_REQUIRE(pv.chunk_cap <= 32, "fst_conv_wgrad: single-tap plan needs chunks of <= 32 channels (got %d)", pv.chunk_cap);
+  }
   const size_t lds_floats = (size_t)p.n_regions * p.region_floats + (TW + 2 + 3) / 4 * 4 + (size_t)pv.MB * 32 * (TW + 1);
   const size_t lds_bytes = lds_floats * sizeof(float);
   FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_conv_wgrad: LDS %zu B exceeds 160 KiB", lds_bytes);
-  void (*fn)(WgradParams) = pv.MB == 8 ? conv_wgrad_kernel<2, TW> : conv_wgrad_kernel<1, TW>;
+  void (*fn)(WgradParams);
+  if (pv.MB == 8) fn = wide ? conv_wgrad_kernel<2, TW, true> : conv_wgrad_kernel<2, TW, false>;
+  else fn = wide ? conv_wgrad_kernel<1, TW, true> : conv_wgrad_kernel<1, TW, false>;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { fst_set_error("fst_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }

@@ -16,6 +16,7 @@ from .plan import Plan, Segment, build_plan, pick_mb
 
 EPI_RELU, EPI_ACC2, EPI_ATOMIC, EPI_ACC1 = 1, 2, 4, 8
 LDS_BUDGET = 96 * 1024
+PIPE_C = 16            # channels per stage of the pipelined conv kernel (csrc/conv_engine.hip)
 
 _PARTIAL_BACKWARD = False
 
@@ -164,9 +165,10 @@ def row_sum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 
 def wgrad_ksplit(B: int, L: int, n_wg_per_slice: int) -> int:
-    """Split (b, t) so that the launch has ≈ 4 workgroups per CU."""
+    """Split (b, t) so that the launch has ≈ 2 workgroups per CU (two fit): every extra slice adds one
+    fp32-atomic pass over the packed gradient, which at ~1.3 TB/s is not free."""
     tiles = B * ((L + 31) // 32)
-    want = max(1, (1024 + n_wg_per_slice - 1) // n_wg_per_slice)
+    want = max(1, (512 + n_wg_per_slice - 1) // n_wg_per_slice)
     return max(1, min(tiles, want))
 
 
@@ -193,9 +195,11 @@ class ConvSpec:
         return (self.ntaps - 1) * self.dil
 
     def nb_for(self, B: int, L: int, mb: int, windowed_c: int, halo: int) -> int:
+        """N-blocks (32 timesteps each) per wave.  windowed_c > 0: the whole-window kernel (omni-scale layers with
+        many taps), whose LDS window must fit; otherwise the pipelined kernel, which has NB ∈ {1, 2}."""
         tiles128 = (L + 127) // 128
         best = 1
-        for nb in (4, 2, 1):
+        for nb in ((4, 2, 1) if windowed_c else (2, 1)):
             if mb * nb > 8 or nb > max(1, tiles128):
                 continue
             if windowed_c and ((windowed_c + 1) & ~1) * (128 * nb + halo) * 4 > LDS_BUDGET:
@@ -211,14 +215,17 @@ class ConvSpec:
             segs.append(Segment(1, self.C1, self.x1_tap, self.x1_tap + 1))
         return segs
 
+    def _windowed(self, channels: int) -> bool:
+        """Many dense taps over few channels (omni-scale layers): stage one [C][T+halo] window and slide the taps
+        over it.  Everything else is cut into single-tap 16-channel stages for the pipelined kernel."""
+        return self.dil == 1 and self.ntaps > 3 and channels <= 64
+
     def _chunking(self, channels: int, nb: int, ntaps: int) -> Tuple[int, bool]:
-        """(chunk_c, split_taps): dilated taps are split so no chunk drags a halo; dense taps share a window."""
-        if self.dil > 1 and ntaps > 1:
-            return 32, True
+        """(chunk_c, split_taps)"""
+        if not self._windowed(channels):
+            return PIPE_C, True
         halo = (ntaps - 1) * self.dil
         cap = (LDS_BUDGET // (4 * (128 * nb + halo))) & ~1
-        if ntaps == 1:
-            cap = min(cap, 64)
         if channels <= cap:
             return (channels + 1) & ~1, False
         n = (channels + cap - 1) // cap
@@ -247,17 +254,19 @@ class ConvSpec:
     def dx1_plan(self, nb: int) -> Plan:
         key = ("dx1", nb)
         if key not in self._plans:
-            self._plans[key] = build_plan(self.C1, [Segment(0, self.M, 0, 1)], 1, 1, 0, chunk_c=64)
+            self._plans[key] = build_plan(self.C1, [Segment(0, self.M, 0, 1)], 1, 1, 0, chunk_c=PIPE_C)
         return self._plans[key]
 
     def wg_plan(self) -> Plan:
         key = ("wg", 0)
         if key not in self._plans:
-            split = self.dil > 1 and self.ntaps > 1
             cmax = max(self.C0, self.C1)
-            chunk_c = 32 if (split or self.ntaps == 1) else (cmax + 1) & ~1
+            if self._windowed(cmax):
+                chunk_c, split = (cmax + 1) & ~1, False           # one [C][32+halo] window, all taps
+            else:
+                chunk_c, split = 32, True                         # single-tap 32-channel chunks = one row-block each
             self._plans[key] = build_plan(self.M, self._fwd_segments(), self.ntaps, self.dil, self.pad_left,
-                                          MB=4 if self.M <= 128 else 8, chunk_c=min(chunk_c, 64), split_taps=split,
+                                          MB=4 if self.M <= 128 else 8, chunk_c=chunk_c, split_taps=split,
                                           row_live=None if self.dense_dw else self.row_live, with_items=True)
         return self._plans[key]
 
@@ -280,7 +289,7 @@ class ConvSpec:
                 y: Optional[Tensor] = None, res: Optional[Tensor] = None, y2: Optional[Tensor] = None,
                 msplit: Optional[int] = None, flags: int = 0) -> Tensor:
         B, L = x0.size(0), x0.size(2)
-        windowed = self.C0 if (self.dil == 1 and self.ntaps > 1 and self.C0 <= 64) else 0
+        windowed = self.C0 if self._windowed(max(self.C0, self.C1)) else 0
         nb = self.nb_for(B, L, self.mb, windowed, self._halo())
         plan = self.fwd_plan(nb)
         a = pack_weights(plan, self.M, w0, self.s_w0(), w1, self.s_w1())
@@ -293,7 +302,7 @@ class ConvSpec:
                 flags: int = 0) -> Tensor:
         B, L = dy.size(0), dy.size(2)
         mb = pick_mb(self.C0)
-        windowed = self.M if (self.dil == 1 and self.ntaps > 1 and self.M <= 64) else 0
+        windowed = self.M if self._windowed(self.M) else 0
         nb = self.nb_for(B, L, mb, windowed, self._halo())
         plan = self.dx0_plan(nb)
         a = pack_weights(plan, self.C0, w0, self.s_w0_T())
@@ -457,8 +466,8 @@ class WNSpecs:
         self.rs = [ConvSpec(2 * n if i < n_layers - 1 else n, n) for i in range(n_layers)]
         self.end = ConvSpec(2 * h, n)
         # dacts = W_rsᵀ·[d_a ; d_out]: rows n, K = 2n channels from two tensors
-        self.rs_T = build_plan(n, [Segment(0, n, 0, 1), Segment(1, n, 0, 1)], 1, 1, 0, chunk_c=64)
-        self.rs_T_last = build_plan(n, [Segment(0, n, 0, 1)], 1, 1, 0, chunk_c=64)
+        self.rs_T = build_plan(n, [Segment(0, n, 0, 1), Segment(1, n, 0, 1)], 1, 1, 0, chunk_c=PIPE_C)
+        self.rs_T_last = build_plan(n, [Segment(0, n, 0, 1)], 1, 1, 0, chunk_c=PIPE_C)
 
 
 class WNFn(torch.autograd.Function):
@@ -681,7 +690,7 @@ def _fixed_matmul(x: Tensor, R: Tensor, M: int, K: int, N: int) -> Tensor:
     """[M,K] @ [K,N] via the conv engine: rows = M, 'channels' = K, 'time' = N."""
     key = (M, K)
     if key not in _matmul_plans:
-        _matmul_plans[key] = build_plan(M, [Segment(0, K, 0, 1)], 1, 1, 0, chunk_c=32)
+        _matmul_plans[key] = build_plan(M, [Segment(0, K, 0, 1)], 1, 1, 0, chunk_c=PIPE_C)
     plan = _matmul_plans[key]
     a = pack_weights(plan, M, x, (0, K, 1, 0))
     n_tiles = (N + 127) // 128

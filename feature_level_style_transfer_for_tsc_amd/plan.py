@@ -142,7 +142,13 @@ def build_plan(M: int, segments: Sequence[Segment], ntaps: int, dil: int = 1, pa
             rec += (hi_q - lo_q) * (c_pad // 2)
             if with_items:
                 n_rb = ((hi_q - lo_q) * c_pad + 31) // 32
+                if hi_q > lo_q + 1:                               # windowed chunk: its own workgroups
+                    while (len(items) - n_before) % WG_ITEMS:
+                        items.append((g, -1, 0, 0))
                 items.extend((g, q, rb, 0) for rb in range(n_rb))
+                if hi_q > lo_q + 1:
+                    while (len(items) - n_before) % WG_ITEMS:
+                        items.append((g, -1, 0, 0))
         if with_items:
             while (len(items) - n_before) % WG_ITEMS:
                 items.append((g, -1, 0, 0))
