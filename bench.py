@@ -64,6 +64,8 @@ def main() -> None:
     ap.add_argument("--length", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph: the whole step is one captured hipGraph replayed per step (default); eager: launch by launch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,30 +100,50 @@ def main() -> None:
     T_half = (args.length // 2) // 2
     torch.manual_seed(4321)                                                   # CPC start indices: same on every rank
 
-    def one_step(i):
-        t = (int(torch.randint(T_half, (1,))), int(torch.randint(T_half, (1,))))
-        return trainer.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=t)
+    def draw_t():
+        return (int(torch.randint(T_half, (1,))), int(torch.randint(T_half, (1,))))
+
+    mode = args.mode
+    if mode == "graph":
+        try:
+            trainer.capture(x_t, y_t, x_s, y_s, epoch=0)
+        except Exception as e:                                                # noqa: BLE001 — report, then run eagerly
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr, flush=True)
+            mode = "eager"
+            torch.cuda.synchronize()
+
+    def one_step():
+        if mode == "graph":
+            return trainer.replay(x_t, y_t, x_s, y_s, draw_t())
+        return trainer.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=draw_t())
 
     for i in range(args.warmup):
-        one_step(i)
+        one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    timer = ops.KernelTimer()
-    ops.KERNEL_TIMER = timer
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        rep = one_step(i)
+        rep = one_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ops.KERNEL_TIMER = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    rep = {k: v.clone() for k, v in rep.items()}
+    # per-kernel durations for the roofline leg: HIP events around every conv-engine launch of ONE extra eager step
+    # (same kernels, same shapes as the timed steps; a captured graph cannot carry timing events)
+    timer = ops.KernelTimer()
+    n_timer_steps = 1
+    if rank == 0:
+        ops.KERNEL_TIMER = timer
+        trainer.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=draw_t())
+        torch.cuda.synchronize()
+        ops.KERNEL_TIMER = None
     ms_per_step = 1e3 * dt / args.steps
     value = world * args.batch * args.steps / dt
 
@@ -130,12 +152,12 @@ def main() -> None:
         dom_key = max(ks, key=lambda k: ks[k]["total_ms"])
         dom = ks[dom_key]
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        conv_ms = sum(v["total_ms"] for v in ks.values()) / args.steps
+        conv_ms = sum(v["total_ms"] for v in ks.values()) / n_timer_steps
         roofline = {"bound": "mfma", "kernel": dom_key, "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches"] / args.steps,
+                    "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches"] / n_timer_steps,
                     "conv_engine_ms_per_step": conv_ms,
-                    "kernels": {k: {"avg_us": round(v["avg_us"], 1), "launches_per_step": v["launches"] / args.steps,
+                    "kernels": {k: {"avg_us": round(v["avg_us"], 1), "launches_per_step": v["launches"] / n_timer_steps,
                                     "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2)} for k, v in ks.items()}}
         line = {"metric": "train-step samples/sec (univariate TS, len=512, batch=256)", "value": value, "unit": "samples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -143,6 +165,7 @@ def main() -> None:
                 "config": {"workload": "configs[1]: full joint step (OS_CNN_res x2 + OS_CNN x3 + WaveGlow(3,50,120) fwd x2 + infer "
                                        "+ CPC x2 + CDAN + GradNorm + RMSprop/Adam), univariate L=%d, %d pairs/GPU" % (args.length, args.batch),
                            "global_batch": world * args.batch, "seq_len": args.length, "parallelism": f"dp{world}"},
+                "mode": mode,
                 "losses": {k: float(rep[k]) for k in ("nf_t", "nf_s", "ce_t", "ce_s", "sl_t", "cdan")},
                 "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:

@@ -24,17 +24,26 @@ class CPC(nn.Module):
         self.Wk = nn.ModuleList([nn.Linear(self.hidden_dim, num_channels) for _ in range(self.timestep)])
         self.lsoftmax = nn.LogSoftmax(dim=-1)
 
-    def forward(self, features: torch.Tensor, t_samples: Optional[int] = None) -> torch.Tensor:
+    def forward(self, features: torch.Tensor, t_samples=None) -> torch.Tensor:
         """``t_samples`` pins the random start (quirk Q6); by default it is drawn from the global CPU RNG
-        exactly as the reference does (:58)."""
+        exactly as the reference does (:58).  It may also be a 0-d int32 DEVICE tensor: then every shape is
+        static (the GRU runs all T/2 steps and its t-th output is gathered), which lets a captured hipGraph
+        replay the step with a new start index each time; results are identical because the GRU is causal."""
         if t_samples is None:
             t_samples = int(torch.randint(self.timestep // 2, size=(1,)).long())
         B, C, L = features.shape
         T = self.timestep
         z = features.transpose(1, 2)
-        output, _ = self.gru(z[:, : t_samples + 1, :].contiguous())
-        c_t = output[:, t_samples, :].reshape(B, self.hidden_dim)
+        if isinstance(t_samples, torch.Tensor):
+            output, _ = self.gru(z[:, : max(1, T // 2), :].contiguous())
+            idx = t_samples.long().view(1, 1, 1).expand(B, 1, self.hidden_dim)
+            c_t = output.gather(1, idx).reshape(B, self.hidden_dim)
+            t0 = (t_samples + 1).to(torch.int32)
+        else:
+            output, _ = self.gru(z[:, : t_samples + 1, :].contiguous())
+            c_t = output[:, t_samples, :].reshape(B, self.hidden_dim)
+            t0 = t_samples + 1
         W = torch.stack([l.weight for l in self.Wk])                          # [T, C, H]
         b = torch.stack([l.bias for l in self.Wk])                            # [T, C]
         pred = torch.baddbmm(b.unsqueeze(1), c_t.unsqueeze(0).expand(T, B, -1), W.transpose(1, 2))   # [T, B, C]
-        return ops.CPCNceFn.apply(features, pred, t_samples + 1, T)
+        return ops.CPCNceFn.apply(features, pred, t0, T)

@@ -456,10 +456,8 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   }
   FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_conv_gemm: LDS window %zu B exceeds 160 KiB (chunk_cap=%d ldw=%d)",
               lds_bytes, pv.chunk_cap, p.ldw);
-  if (lds_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { fst_set_error("fst_conv_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-  }
+  if (lds_bytes > 48 * 1024)
+    if (int rc = fst_allow_full_lds((const void*)fn, "fst_conv_gemm")) return rc;
   dim3 grid((unsigned)(B * p.tiles_per_seq), (unsigned)((pv.n_mgroups + p.mg_per_wg - 1) / p.mg_per_wg), (unsigned)ksplit);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
@@ -763,10 +761,8 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   void (*fn)(WgradParams);
   if (pv.MB == 8) fn = wide ? conv_wgrad_kernel<2, TW, true> : conv_wgrad_kernel<2, TW, false>;
   else fn = wide ? conv_wgrad_kernel<1, TW, true> : conv_wgrad_kernel<1, TW, false>;
-  if (lds_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { fst_set_error("fst_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-  }
+  if (lds_bytes > 48 * 1024)
+    if (int rc = fst_allow_full_lds((const void*)fn, "fst_conv_wgrad")) return rc;
   dim3 grid((unsigned)p.ksplit, (unsigned)(pv.n_items / WG_ITEMS), 1);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();

@@ -30,11 +30,13 @@ struct CpcParams {
   const float* gout;   // scalar upstream gradient of nce (device), bwd only
   float* denc;         // same strides as enc
   float* dpred;        // [T][B][C]
+  const int* t0_dev;   // optional device scalar: extra time offset of enc/denc (elements of stride s_i)
   int T, B, C;
 };
 
 __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.t0_dev) p.enc += (long long)p.t0_dev[0] * p.s_i;
   const int i = blockIdx.x, r0 = blockIdx.y * CPC_ROWS;
   const int B = p.B, C = p.C, PS = C | 1;
   float* predl = lds;                 // [B][PS]
@@ -87,6 +89,10 @@ __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
 template <int CMAX>
 __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (p.t0_dev) {
+    p.enc += (long long)p.t0_dev[0] * p.s_i;
+    p.denc += (long long)p.t0_dev[0] * p.s_i;
+  }
   const int i = blockIdx.x;
   const int B = p.B, C = p.C, PS = C | 1;
   float* predl = lds;                              // [B][PS]
@@ -163,27 +169,27 @@ static int cpc_check(const CpcParams& p, size_t lds_bytes, const char* who) {
   return 0;
 }
 
-extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const float* pred, int T, int B,
-                               int C, float* lse, float* nce_sum, void* stream) {
+extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev,
+                               const float* pred, int T, int B, int C, float* lse, float* nce_sum, void* stream) {
   CpcParams p = {};
+  p.t0_dev = t0_dev;
   p.enc = enc; p.s_i = s_i; p.s_b = s_b; p.s_c = s_c; p.pred = pred; p.lse = lse; p.nce_sum = nce_sum;
   p.T = T; p.B = B; p.C = C;
   const size_t lds_bytes = ((size_t)B * (C | 1) + CPC_ROWS * C) * sizeof(float);
   if (int rc = cpc_check(p, lds_bytes, "fst_cpc_nce_fwd")) return rc;
   FST_REQUIRE(nce_sum, "fst_cpc_nce_fwd: nce_sum is null");
-  if (lds_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)cpc_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { fst_set_error("fst_cpc_nce_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-  }
+  if (lds_bytes > 48 * 1024)
+    if (int rc = fst_allow_full_lds((const void*)cpc_fwd_kernel, "fst_cpc_nce_fwd")) return rc;
   hipLaunchKernelGGL(cpc_fwd_kernel, dim3(T, (B + CPC_ROWS - 1) / CPC_ROWS), dim3(256), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const float* pred,
-                               const float* lse, int T, int B, int C, const float* gout, float* denc, float* dpred,
-                               void* stream) {
+extern "C" int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev,
+                               const float* pred, const float* lse, int T, int B, int C, const float* gout, float* denc,
+                               float* dpred, void* stream) {
   CpcParams p = {};
+  p.t0_dev = t0_dev;
   p.enc = enc; p.s_i = s_i; p.s_b = s_b; p.s_c = s_c; p.pred = pred; p.lse = const_cast<float*>(lse);
   p.gout = gout; p.denc = denc; p.dpred = dpred; p.T = T; p.B = B; p.C = C;
   const size_t lds_bytes = ((size_t)B * (C | 1) + CPC_ROWS * C + (size_t)CPC_ROWS * B) * sizeof(float);
@@ -192,10 +198,8 @@ extern "C" int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64
   FST_REQUIRE(B <= 256, "fst_cpc_nce_bwd: B=%d > 256 negatives per rank not supported yet", B);
   FST_REQUIRE(C <= 128, "fst_cpc_nce_bwd: C=%d > 128 not supported yet", C);
   void (*fn)(CpcParams) = C <= 32 ? cpc_bwd_kernel<32> : (C <= 64 ? cpc_bwd_kernel<64> : cpc_bwd_kernel<128>);
-  if (lds_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { fst_set_error("fst_cpc_nce_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-  }
+  if (lds_bytes > 48 * 1024)
+    if (int rc = fst_allow_full_lds((const void*)fn, "fst_cpc_nce_bwd")) return rc;
   hipLaunchKernelGGL(fn, dim3(T), dim3(256), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;

@@ -52,5 +52,9 @@ static inline int plan_expected_len(const int32_t* p) {
   return FST_PLAN_HDR + 4 * p[0] + 4 * p[0] * p[1] + 4 * p[8];
 }
 
+// Raise a kernel's dynamic-LDS limit to the full 160 KiB once (idempotent; never called again for that kernel,
+// so nothing but launches happens while a stream is being captured into a hipGraph).
+int fst_allow_full_lds(const void* fn, const char* who);
+
 // Host-side sanity check of a plan against the tensor shapes a launch will touch.
 int fst_check_plan(const int32_t* plan_host, int plan_len, int M, const char* who);

@@ -11,6 +11,20 @@ void fst_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* fst_last_error(void) { return g_err; }
+
+int fst_allow_full_lds(const void* fn, const char* who) {
+  static const void* done[64];
+  static int n_done = 0;
+  for (int i = 0; i < n_done; ++i)
+    if (done[i] == fn) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    fst_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+    return (int)e;
+  }
+  if (n_done < 64) done[n_done++] = fn;
+  return 0;
+}
 extern "C" int fst_version(void) { return FST_ABI_VERSION; }
 
 __device__ __forceinline__ float wave_sum(float v) {

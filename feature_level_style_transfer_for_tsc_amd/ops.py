@@ -101,8 +101,39 @@ def _wsrc(t: Optional[Tensor], off0: int, sm: int, sc: int, st: int) -> WSrc:
 # --------------------------------------------------------------------------------------------------
 # raw launches
 # --------------------------------------------------------------------------------------------------
+_PACK_CACHE: Optional[dict] = None
+
+
+class pack_cache:
+    """Context: within one train step the weights do not change, so each (plan, weight view) is packed once
+    and reused by every forward / data-gradient call of the step (three WaveGlow passes, GradNorm's partial
+    backward passes).  Entries keep their source tensors alive, so a data pointer cannot be recycled."""
+
+    def __enter__(self):
+        global _PACK_CACHE
+        self._prev, _PACK_CACHE = _PACK_CACHE, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_CACHE
+        _PACK_CACHE = self._prev
+        return False
+
+
 def pack_weights(plan: Plan, M: int, w0: Tensor, s0: Tuple[int, int, int, int], w1: Optional[Tensor] = None,
                  s1: Tuple[int, int, int, int] = (0, 0, 0, 0)) -> Tensor:
+    if _PACK_CACHE is not None:
+        key = (id(plan), M, w0.data_ptr(), w0._version, s0, None if w1 is None else (w1.data_ptr(), w1._version), s1)
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            return hit[0]
+        a = _pack_weights(plan, M, w0, s0, w1, s1)
+        _PACK_CACHE[key] = (a, w0, w1, plan)
+        return a
+    return _pack_weights(plan, M, w0, s0, w1, s1)
+
+
+def _pack_weights(plan: Plan, M: int, w0: Tensor, s0, w1: Optional[Tensor], s1) -> Tensor:
     lib = _lib.load()
     a = torch.empty(plan.packed_floats, device=w0.device, dtype=torch.float32)
     src0 = _wsrc(w0, *s0)
@@ -629,21 +660,26 @@ class CouplingInvFn(torch.autograd.Function):
 # CPC InfoNCE
 # --------------------------------------------------------------------------------------------------
 class CPCNceFn(torch.autograd.Function):
-    """nce = −(1/(B·T)) Σ_i Σ_b log_softmax(enc_i·pred_iᵀ)[b,b]; enc_i[b,c] = feat[b,c,t0+i] read in place."""
+    """nce = −(1/(B·T)) Σ_i Σ_b log_softmax(enc_i·pred_iᵀ)[b,b]; enc_i[b,c] = feat[b,c,t0+i] read in place.
+    ``t0`` is a Python int or a 0-d int32 DEVICE tensor (so a captured hipGraph can vary it between replays)."""
 
     @staticmethod
-    def forward(ctx, feat: Tensor, pred: Tensor, t0: int, T: int):
+    def forward(ctx, feat: Tensor, pred: Tensor, t0, T: int):
         lib = _lib.load()
         _lib.require_gpu_tensor(feat, "feat")
         feat, pred = feat.contiguous(), pred.contiguous()
         B, C, L = feat.shape
-        assert pred.shape == (T, B, C) and t0 + T <= L
+        assert pred.shape == (T, B, C)
+        t0_dev = t0 if isinstance(t0, torch.Tensor) else None
+        t0_host = 0 if t0_dev is not None else int(t0)
+        assert t0_dev is None or (t0_dev.dtype == torch.int32 and t0_dev.is_cuda)
+        assert t0_host + T <= L
         lse = torch.empty(T, B, device=feat.device, dtype=torch.float32)
         acc = torch.zeros((), device=feat.device, dtype=torch.float32)
-        check(lib.fst_cpc_nce_fwd(feat.data_ptr() + 4 * t0, 1, C * L, L, ptr(pred), T, B, C, ptr(lse), ptr(acc),
-                                  stream_ptr()), "fst_cpc_nce_fwd")
+        check(lib.fst_cpc_nce_fwd(feat.data_ptr() + 4 * t0_host, 1, C * L, L, ptr(t0_dev), ptr(pred), T, B, C, ptr(lse),
+                                  ptr(acc), stream_ptr()), "fst_cpc_nce_fwd")
         ctx.save_for_backward(feat, pred, lse)
-        ctx.t0, ctx.T = t0, T
+        ctx.t0_host, ctx.t0_dev, ctx.T = t0_host, t0_dev, T
         return acc * (-1.0 / (B * T))
 
     @staticmethod
@@ -651,12 +687,12 @@ class CPCNceFn(torch.autograd.Function):
         lib = _lib.load()
         feat, pred, lse = ctx.saved_tensors
         B, C, L = feat.shape
-        T, t0 = ctx.T, ctx.t0
+        T, t0 = ctx.T, ctx.t0_host
         dfeat = torch.zeros_like(feat)
         dpred = torch.empty_like(pred)
         g = g.contiguous().float()
-        check(lib.fst_cpc_nce_bwd(feat.data_ptr() + 4 * t0, 1, C * L, L, ptr(pred), ptr(lse), T, B, C, ptr(g),
-                                  dfeat.data_ptr() + 4 * t0, ptr(dpred), stream_ptr()), "fst_cpc_nce_bwd")
+        check(lib.fst_cpc_nce_bwd(feat.data_ptr() + 4 * t0, 1, C * L, L, ptr(ctx.t0_dev), ptr(pred), ptr(lse), T, B, C,
+                                  ptr(g), dfeat.data_ptr() + 4 * t0, ptr(dpred), stream_ptr()), "fst_cpc_nce_bwd")
         return dfeat, dpred, None, None
 
 

@@ -127,12 +127,13 @@ class JointTrainer:
         self.m = {k: v.to(device) for k, v in m.items()}
         self.random_layer = self.random_layer.to(device)
         self.nf_loss = WaveGlowLoss()
-        self.opts = {k: torch.optim.RMSprop(self.m[k].parameters(), lr=lr) for k, lr in self.LRS.items()}
-        self.opt_cpc = torch.optim.Adam(self.m["cpc"].parameters(), lr=0.002)
+        # capturable=True keeps the optimiser step counters on the device (needed under hipGraph capture)
+        self.opts = {k: torch.optim.RMSprop(self.m[k].parameters(), lr=lr, capturable=True) for k, lr in self.LRS.items()}
+        self.opt_cpc = torch.optim.Adam(self.m["cpc"].parameters(), lr=0.002, capturable=True)
         self.w_t = nn.Parameter(torch.tensor([2.0, 5.0], device=device))         # :501-505
         self.w_s = nn.Parameter(torch.tensor([2.0, 2.0, 4.0], device=device))
-        self.opt_w_t = torch.optim.Adam([self.w_t], lr=0.0002)
-        self.opt_w_s = torch.optim.Adam([self.w_s], lr=0.001)
+        self.opt_w_t = torch.optim.Adam([self.w_t], lr=0.0002, capturable=True)
+        self.opt_w_s = torch.optim.Adam([self.w_s], lr=0.001, capturable=True)
         self.init_t = self.init_s = None
         self.alpha = 3
         self.on_grads_ready = None                                            # test hook: called before the optimisers step
@@ -155,8 +156,44 @@ class JointTrainer:
             self.random_layer.random_matrix = [t.to(self.device) for t in mats]
             self.random_layer._transposed = {}
 
+    # ------------------------------------------------------------------ state snapshot (in-place restore keeps addresses)
+    def _state_tensors(self):
+        out = {}
+        for k in self.MODULES:
+            for n, t in self.m[k].state_dict().items():
+                out[f"m.{k}.{n}"] = t
+        opts = dict(self.opts)
+        opts.update({"cpc": self.opt_cpc, "w_t": self.opt_w_t, "w_s": self.opt_w_s})
+        for k, o in opts.items():
+            for gi, group in enumerate(o.param_groups):
+                for pi, p in enumerate(group["params"]):
+                    for n, t in o.state.get(p, {}).items():
+                        if isinstance(t, torch.Tensor):
+                            out[f"o.{k}.{gi}.{pi}.{n}"] = t
+        out["w_t"], out["w_s"] = self.w_t.data, self.w_s.data
+        out["noise.target_avg"], out["noise.source_avg"] = self.m["noise"].target_avg, self.m["noise"].source_avg
+        if self.init_t is not None:
+            out["init_t"], out["init_s"] = self.init_t, self.init_s
+        return out
+
+    def snapshot(self):
+        """Copy of every tensor the step mutates (parameters, BN buffers, optimiser moments, GradNorm weights,
+        NoiseTransfer sums) plus the host-side counters."""
+        host = {"noise": (self.m["noise"].time, self.m["noise"].cal_num_target, self.m["noise"].cal_num_source),
+                "ad": self.m["ad_net"].iter_num, "fd": self.m["fd_s"].iter_num}
+        return {"t": {k: v.detach().clone() for k, v in self._state_tensors().items()}, "host": host}
+
+    def restore(self, snap) -> None:
+        cur = self._state_tensors()
+        with torch.no_grad():
+            for k, v in snap["t"].items():
+                cur[k].copy_(v)
+        n = self.m["noise"]
+        n.time, n.cal_num_target, n.cal_num_source = snap["host"]["noise"]
+        self.m["ad_net"].iter_num, self.m["fd_s"].iter_num = snap["host"]["ad"], snap["host"]["fd"]
+
     # ------------------------------------------------------------------ forward (train_and_test.py:547-603)
-    def forward_losses(self, x_t, y_t, x_s, y_s, t_samples=(None, None)):
+    def forward_losses(self, x_t, y_t, x_s, y_s, t_samples=(None, None), noise_ratios=None):
         m = self.m
         feat_t = m["fe_t"](x_t)
         sl_t = m["cpc"](feat_t, t_samples[0])
@@ -164,7 +201,7 @@ class JointTrainer:
         sl_s = m["cpc"](feat_s, t_samples[1])
         out_t, out_s = m["nf"](feat_t), m["nf"](feat_s)
         nf_t, nf_s = self.nf_loss(out_t), self.nf_loss(out_s)
-        z_s2t = m["noise"](out_t[0], out_s[0])
+        z_s2t = m["noise"](out_t[0], out_s[0], noise_ratios)
         feat_s2t = m["nf"].infer(z_s2t)
         logit_t, pool_t = m["clf_t"](feat_t)
         m["clf_t"].eval()                                                     # :584-586
@@ -183,14 +220,24 @@ class JointTrainer:
 
     # ------------------------------------------------------------------ one optimisation step (:645-766)
     def step(self, x_t, y_t, x_s, y_s, epoch: int = 0, t_samples=(None, None)):
-        L, aux = self.forward_losses(x_t, y_t, x_s, y_s, t_samples)
+        """Eager step.  ``t_samples``: the two CPC start indices (drawn like the reference if None)."""
+        ratios = self.m["noise"].advance(x_t.size(0), x_s.size(0))
+        return self._step_body(x_t, y_t, x_s, y_s, epoch, t_samples, ratios)
+
+    def _step_body(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
+        """Everything device-side and shape-static, so it runs eagerly or under hipGraph capture unchanged."""
+        with ops.pack_cache(), self.m["nf"].shared_fold():
+            return self._step_impl(x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios)
+
+    def _step_impl(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
+        L, aux = self.forward_losses(x_t, y_t, x_s, y_s, t_samples, noise_ratios)
         lt = torch.stack([L["nf_t"], L["ce_t"]])
         ls = torch.stack([L["nf_s"], L["ce_s"], L["ce_s2t2s"]])
         lt_v, ls_v = lt.detach(), ls.detach()
         if self.bucket is not None:                                           # keep GradNorm identical on all ranks
             lt_v, ls_v = self.bucket.mean_scalars(lt_v), self.bucket.mean_scalars(ls_v)
         if self.init_t is None:                                               # :658-664
-            self.init_t, self.init_s = torch.sigmoid(lt_v), torch.sigmoid(ls_v)
+            self.init_t, self.init_s = torch.sigmoid(lt_v).clone(), torch.sigmoid(ls_v).clone()
         a, b, c, d = loss_coefficients(epoch)
         # Q3: first backward + second backward (weights zeroed) == Σ wᵢ∇Lᵢ + 2·(a∇cdan + b∇fd + c∇sl_t + d∇sl_s)
         total = torch.sum(self.w_t.detach() * lt) + torch.sum(self.w_s.detach() * ls) \
@@ -221,7 +268,10 @@ class JointTrainer:
 
         if self.bucket is not None:
             self.bucket.all_reduce(self.parameters())
-        self.w_t.grad, self.w_s.grad = g_w_t, g_w_s
+        for w, g in ((self.w_t, g_w_t), (self.w_s, g_w_s)):                   # static .grad buffers (graph-safe)
+            if w.grad is None:
+                w.grad = torch.zeros_like(w)
+            w.grad.copy_(g)
         if self.on_grads_ready is not None:
             self.on_grads_ready()
         self.opt_w_t.step(); self.opt_w_s.step()
@@ -242,3 +292,54 @@ class JointTrainer:
         report.update({"w_t": self.w_t.detach().clone(), "w_s": self.w_s.detach().clone(),
                        "norms_t": nt.detach(), "norms_s": ns.detach()})
         return report
+
+    # ------------------------------------------------------------------ hipGraph: capture once, replay per step
+    def capture(self, x_t, y_t, x_s, y_s, epoch: int = 0, warmup: int = 11):
+        """Capture one whole step (≈10 k launches: forward, GradNorm partial backwards, backward, optimisers)
+        into a hipGraph.  Per-step inputs live in static device buffers that ``replay`` refreshes: the batch,
+        the two CPC start indices and NoiseTransfer's two accumulation ratios.  The GRL coefficients are
+        Python floats baked in at capture, so the warm-up runs until their call counters saturate
+        (20 calls, i.e. 10 steps — quirk Q7); the epoch-dependent loss coefficients are baked too, so
+        re-capture when ``loss_coefficients(epoch)`` changes."""
+        dev = self.device
+        self._g_in = {"x_t": x_t.clone(), "y_t": y_t.clone(), "x_s": x_s.clone(), "y_s": y_s.clone(),
+                      "t": torch.zeros(2, dtype=torch.int32, device=dev), "r": torch.ones(2, device=dev)}
+        self._g_epoch = epoch
+        T_half = max(1, (self.cfg.L_t // 2) // 2)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                         # eager warm-up on a side stream
+            for _ in range(warmup):
+                self._replay_inputs(x_t, y_t, x_s, y_s, (int(torch.randint(T_half, (1,))), int(torch.randint(T_half, (1,)))))
+                self._graph_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if self.m["ad_net"].iter_num < self.m["ad_net"].max_iter or self.m["fd_s"].iter_num < self.m["fd_s"].max_iter:
+            raise RuntimeError("capture(): GRL call counters not saturated yet; increase warmup")
+        self._graph = torch.cuda.CUDAGraph()
+        self._replay_inputs(x_t, y_t, x_s, y_s, (0, 0))
+        with torch.cuda.graph(self._graph):
+            self._g_out = self._graph_body()
+        return self
+
+    def _graph_body(self):
+        gi = self._g_in
+        return self._step_body(gi["x_t"], gi["y_t"], gi["x_s"], gi["y_s"], self._g_epoch, (gi["t"][0], gi["t"][1]),
+                               (gi["r"][0], gi["r"][1]))
+
+    def _replay_inputs(self, x_t, y_t, x_s, y_s, t_samples):
+        gi = self._g_in
+        for k, v in (("x_t", x_t), ("y_t", y_t), ("x_s", x_s), ("y_s", y_s)):
+            if v is not gi[k]:
+                gi[k].copy_(v, non_blocking=True)
+        ratios = self.m["noise"].advance(x_t.size(0), x_s.size(0))
+        host = torch.tensor([float(t_samples[0]), float(t_samples[1]), ratios[0], ratios[1]], dtype=torch.float64)
+        dev = host.to(self.device, non_blocking=True)
+        gi["t"].copy_(dev[:2])
+        gi["r"].copy_(dev[2:])
+
+    def replay(self, x_t, y_t, x_s, y_s, t_samples):
+        """One step through the captured graph; returns the (static) report tensors."""
+        self._replay_inputs(x_t, y_t, x_s, y_s, t_samples)
+        self._graph.replay()
+        return self._g_out

@@ -68,8 +68,19 @@ class WN(nn.Module):
                                            padding=int((kernel_size * d - d) / 2)))
             self.res_skip_layers.append(_wn_conv(n_channels, 2 * n_channels if i < n_layers - 1 else n_channels, 1))
         self.specs = ops.WNSpecs(n_in_channels, n_channels, n_layers, kernel_size)
+        self._fold_cache = None
 
     def folded_weights(self) -> List[torch.Tensor]:
+        """Effective weights g·v/‖v‖.  Inside ``WaveGlow.shared_fold()`` (one train step: the weights are the same
+        for the two forward passes and ``infer``) the fold is done once and its autograd graph is shared."""
+        if self._fold_cache is not None and self._fold_cache[0]:
+            return self._fold_cache[0]
+        w = self._fold()
+        if self._fold_cache is not None:
+            self._fold_cache[0] = w
+        return w
+
+    def _fold(self) -> List[torch.Tensor]:
         w = [_folded(self.start), self.start.bias, _folded(self.cond_layer), self.cond_layer.bias,
              self.end.weight, self.end.bias]
         w += [_folded(l) for l in self.in_layers] + [l.bias for l in self.in_layers]
@@ -92,6 +103,24 @@ class WaveGlow(nn.Module):
         for _ in range(n_flows):
             self.convinv.append(Invertible1x1Conv(n_group))
             self.WN.append(WN(n_group // 2, 8, n_channels_for_WN, 3))
+
+    class _SharedFold:
+        def __init__(self, wg):
+            self.wg = wg
+
+        def __enter__(self):
+            for wn in self.wg.WN:
+                wn._fold_cache = [None]
+            return self
+
+        def __exit__(self, *exc):
+            for wn in self.wg.WN:
+                wn._fold_cache = None
+            return False
+
+    def shared_fold(self):
+        """Context manager: fold the weight-norm parameters once for every pass made inside it."""
+        return WaveGlow._SharedFold(self)
 
     def forward(self, forward_input: torch.Tensor):
         audio = forward_input

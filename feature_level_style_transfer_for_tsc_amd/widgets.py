@@ -135,19 +135,27 @@ class NoiseTransfer(nn.Module):
         self.target_avg, self.source_avg = fn(self.target_avg), fn(self.source_avg)
         return super()._apply(fn, *a, **k)
 
-    def forward(self, target_noise_batch, source_noise_batch):
+    def advance(self, batch_target: int, batch_source: int):
+        """Host-side bookkeeping of one call (:151-161): returns the two accumulation ratios
+        (1 on the first call, B/N_seen afterwards — Q5) and bumps the counters."""
         self.time += 1
-        bt, bs = target_noise_batch.size(0), source_noise_batch.size(0)
         if self.time == 1:
-            self.target_avg = self.target_avg + torch.mean(target_noise_batch, dim=0)
-            self.source_avg = self.source_avg + torch.mean(source_noise_batch, dim=0)
+            ratios = (1.0, 1.0)
         else:
-            self.target_avg = self.target_avg + (bt / self.cal_num_target) * torch.mean(target_noise_batch, dim=0)
-            self.source_avg = self.source_avg + (bs / self.cal_num_source) * torch.mean(source_noise_batch, dim=0)
-        self.cal_num_target += bt
-        self.cal_num_source += bs
-        general_distance = self.target_avg - self.source_avg
+            ratios = (batch_target / self.cal_num_target, batch_source / self.cal_num_source)
+        self.cal_num_target += batch_target
+        self.cal_num_source += batch_source
+        return ratios
+
+    def forward(self, target_noise_batch, source_noise_batch, ratios=None):
+        """``ratios``: optional pair of 0-d DEVICE tensors holding this call's accumulation ratios; a captured
+        hipGraph passes static buffers that the host refreshes (via ``advance``) before every replay."""
+        if ratios is None:
+            ratios = self.advance(target_noise_batch.size(0), source_noise_batch.size(0))
+        new_target = self.target_avg + ratios[0] * torch.mean(target_noise_batch, dim=0)
+        new_source = self.source_avg + ratios[1] * torch.mean(source_noise_batch, dim=0)
+        general_distance = new_target - new_source
         learned = self.activation_selu(self.apply_learnable_weight(general_distance))   # unbatched [C, L] conv
-        self.source_avg = self.source_avg.detach()
-        self.target_avg = self.target_avg.detach()
+        self.target_avg.copy_(new_target.detach())                # state is kept detached, in place
+        self.source_avg.copy_(new_source.detach())
         return learned + source_noise_batch

@@ -145,13 +145,14 @@ int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, con
  * total_i = enc_i·pred_iᵀ (B×B, K=C); nce_sum = Σ_i Σ_b log_softmax(total_i)[b,b]  (the caller
  * multiplies by −1/(B·T)).  enc element (i,b,c) is read in place at enc[i*s_i + b*s_b + c*s_c]
  * (a strided view of the [B,C,L] feature tensor); pred is [T,B,C] contiguous; lse [T,B] is kept
- * for backward.  gout is the DEVICE scalar d loss / d nce.
+ * for backward.  gout is the DEVICE scalar d loss / d nce.  t0_dev (optional DEVICE int32 scalar) adds
+ * t0_dev[0]·s_i elements to enc/denc, so the random start index can change between hipGraph replays.
  * ------------------------------------------------------------------------------------------- */
-int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const float* pred,
-                    int T, int B, int C, float* lse, float* nce_sum /* scalar, zeroed */, void* stream);
-int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const float* pred, const float* lse,
-                    int T, int B, int C, const float* gout, float* denc /* same strides as enc */,
-                    float* dpred, void* stream);
+int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
+                    const float* pred, int T, int B, int C, float* lse, float* nce_sum /* scalar, zeroed */, void* stream);
+int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
+                    const float* pred, const float* lse, int T, int B, int C, const float* gout,
+                    float* denc /* same strides as enc */, float* dpred, void* stream);
 
 #ifdef __cplusplus
 }

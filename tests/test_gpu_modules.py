@@ -216,6 +216,30 @@ def test_joint_step_golden():
             close(grads[name][k], v, 2e-3, f"Q3 grad {name}.{k}", scale=scale)
 
 
+def test_hipgraph_replay_matches_eager_step():
+    """The captured step (one hipGraph replay) must equal the eager step from the same state, and its
+    per-replay inputs (batch, CPC start indices) must be live."""
+    g = load("joint_small")
+    tr = _joint_trainer(g)
+    args = [torch.tensor(g[f"s0.{k}"], device=DEV) for k in ("x_t", "y_t", "x_s", "y_s")]
+    torch.manual_seed(5)
+    tr.capture(*args, epoch=0)
+    snap = tr.snapshot()
+    rep = {k: v.clone() for k, v in tr.replay(*args, (3, 5)).items()}
+    after_graph = tr.snapshot()
+    tr.restore(snap)
+    eager = tr.step(*args, epoch=0, t_samples=(3, 5))
+    for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s"):
+        assert abs(rep[k].item() - eager[k].item()) <= 1e-4 * max(1.0, abs(eager[k].item())), (k, rep[k].item(), eager[k].item())
+    close(rep["logit_s2t"], eager["logit_s2t"], 1e-4, "graph vs eager logit_s2t")
+    close(rep["w_t"], eager["w_t"], 1e-4, "graph vs eager w_t")
+    after_eager = tr.snapshot()
+    for k in ("m.fe_t.net_1.net.net.1.conv1d.weight", "m.nf.WN.0.in_layers.3.weight_v", "m.cpc.Wk.0.weight", "w_s"):
+        close(after_graph["t"][k], after_eager["t"][k], 2e-3, "post-step " + k)
+    other = tr.replay(*args, (1, 2))
+    assert abs(other["sl_t"].item() - rep["sl_t"].item()) > 1e-6      # a different CPC start index is really used
+
+
 # ------------------------------------------------------------------ oracle on fresh inputs, metric shapes
 def test_waveglow_metric_width_vs_oracle():
     """WaveGlow(3, 50, 120) — the real widths — forward loss, backward and infer vs the CPU oracle (B=2, L=512)."""
