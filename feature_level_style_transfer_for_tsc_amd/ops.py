@@ -165,7 +165,8 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
                             plan.length, ptr(bias), ptr(y), y_bs, ptr(res), res_bs, ptr(y2), y2_bs, msplit, B, L, M,
                             nb, ksplit, flags, stream_ptr()), "fst_conv_gemm")
     if t0 is not None:
-        KERNEL_TIMER.end(f"conv_gemm_kernel<{plan.MB}, {nb}>", t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
+        name = "conv_gemm_pipe_kernel" if (plan.pipeable and nb <= 2) else "conv_gemm_kernel"
+        KERNEL_TIMER.end(f"{name}<{plan.MB}, {nb}>", t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
 
 
 def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor], msplit: int, B: int,
@@ -181,7 +182,9 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
                              ptr(plan.dev(x0.device)), plan.host_ptr(), plan.length, B, L, M, ksplit, stream_ptr()),
           "fst_conv_wgrad")
     if t0 is not None:
-        KERNEL_TIMER.end(f"conv_wgrad_kernel<{plan.MB // 4}, 32>", t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
+        wide = bool(((plan.entries()[:, :, 1] - plan.entries()[:, :, 0]) > 1).any())
+        KERNEL_TIMER.end(f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}>", t0,
+                         2.0 * B * L * _plan_macs_per_step(plan, M))
     return da
 
 

@@ -67,6 +67,13 @@ class Plan:
     def host_ptr(self) -> int:
         return int(self.table.ctypes.data)
 
+    @property
+    def pipeable(self) -> bool:
+        """True if fst_conv_gemm dispatches this plan to the software-pipelined kernel (mirrors
+        plan_is_pipeable in csrc/conv_engine.hip): single-tap stages of at most 16 channels."""
+        en = self.entries()
+        return self.chunk_cap <= 16 and bool(((en[:, :, 1] - en[:, :, 0]) <= 1).all())
+
     def dev(self, device):
         """int32 copy of the table on ``device`` (cached)."""
         import torch
