@@ -31,7 +31,7 @@ struct ConvGemmParams {
   long long res_bs;
   float* y2;
   long long y2_bs;
-  int msplit;
+  int msplit, m2_start;
   int B, L, M;
   int tiles_per_seq, ksplit, flags, mg_per_wg, ldw;
 };
@@ -145,9 +145,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
           dst = p.y + (long long)b * p.y_bs + (long long)m * L;
           if (p.res) resp = p.res + (long long)b * p.res_bs + (long long)m * L;
           accum = (p.flags & FST_EPI_ACC1) != 0;
-        } else {
-          dst = p.y2 + (long long)b * p.y2_bs + (long long)(m - p.msplit) * L;
+        } else if (m >= p.m2_start) {
+          dst = p.y2 + (long long)b * p.y2_bs + (long long)(m - p.m2_start) * L;
           accum = (p.flags & FST_EPI_ACC2) != 0;
+        } else {
+          continue;   // padding rows between the two outputs
         }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -301,9 +303,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p
         dst = p.y + (long long)b * p.y_bs + (long long)m * L;
         if (p.res) resp = p.res + (long long)b * p.res_bs + (long long)m * L;
         accum = (p.flags & FST_EPI_ACC1) != 0;
-      } else {
-        dst = p.y2 + (long long)b * p.y2_bs + (long long)(m - p.msplit) * L;
+      } else if (m >= p.m2_start) {
+        dst = p.y2 + (long long)b * p.y2_bs + (long long)(m - p.m2_start) * L;
         accum = (p.flags & FST_EPI_ACC2) != 0;
+      } else {
+        continue;   // padding rows between the two outputs
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
@@ -404,7 +408,7 @@ int fst_check_plan(const int32_t* ph, int plan_len, int M, const char* who) {
 extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs, const float* a_packed,
                              const int32_t* plan_dev, const int32_t* plan_host, int plan_len, const float* bias,
                              float* y, int64_t y_bs, const float* res, int64_t res_bs, float* y2, int64_t y2_bs,
-                             int msplit, int B, int L, int M, int nb_cfg, int ksplit, int flags, void* stream) {
+                             int msplit, int m2_start, int B, int L, int M, int nb_cfg, int ksplit, int flags, void* stream) {
   if (int rc = fst_check_plan(plan_host, plan_len, M, "fst_conv_gemm")) return rc;
   const PlanView pv = plan_view(plan_host);
   FST_REQUIRE(x0 && a_packed && plan_dev, "fst_conv_gemm: null operand");
@@ -412,6 +416,7 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   FST_REQUIRE(msplit >= 0 && msplit <= M, "fst_conv_gemm: msplit=%d outside [0,%d]", msplit, M);
   FST_REQUIRE(msplit == 0 || y != nullptr, "fst_conv_gemm: y is null but msplit=%d", msplit);
   FST_REQUIRE(msplit == M || y2 != nullptr, "fst_conv_gemm: y2 is null but msplit=%d < M=%d", msplit, M);
+  FST_REQUIRE(m2_start >= msplit && m2_start <= M, "fst_conv_gemm: m2_start=%d outside [msplit=%d, M=%d]", m2_start, msplit, M);
   FST_REQUIRE(ksplit >= 1 && ksplit <= pv.n_chunks, "fst_conv_gemm: ksplit=%d vs %d chunks", ksplit, pv.n_chunks);
   FST_REQUIRE(ksplit == 1 || (flags & FST_EPI_ATOMIC), "fst_conv_gemm: ksplit>1 needs FST_EPI_ATOMIC");
   bool needs_x1 = false;
@@ -426,6 +431,7 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   p.x[0] = x0; p.x[1] = x1; p.x_bs[0] = x0_bs; p.x_bs[1] = x1_bs;
   p.a = a_packed; p.plan = plan_dev; p.bias = bias;
   p.y = y; p.y_bs = y_bs; p.res = res; p.res_bs = res_bs; p.y2 = y2; p.y2_bs = y2_bs; p.msplit = msplit;
+  p.m2_start = m2_start;
   p.B = B; p.L = L; p.M = M;
   p.tiles_per_seq = (L + TILE_N - 1) / TILE_N;
   p.ksplit = ksplit; p.flags = flags;
@@ -777,13 +783,14 @@ struct PackParams {
   fst_wsrc src[2];
   float* dst[2];       // unpack targets
   float* a;            // packed buffer (written by pack, read by unpack)
-  int M;
+  int M;               // rows [row_base, M) are valid; the weight view is indexed with m - row_base
   int unpack;
+  int g_begin, g_end, row_base;
 };
 
 __global__ __launch_bounds__(256) void pack_kernel(PackParams p) {
   const PlanView pv = plan_view(p.plan);
-  const int gq = blockIdx.y;
+  const int gq = blockIdx.y + p.g_begin * pv.n_chunks;
   const int g = gq / pv.n_chunks, q = gq - g * pv.n_chunks;
   const int32_t* e = pv.mg + 4 * gq;
   const int32_t* c = pv.chunk + 4 * q;
@@ -800,8 +807,8 @@ __global__ __launch_bounds__(256) void pack_kernel(PackParams p) {
     const int tapi = rec / half_c, cp = rec - tapi * half_c;
     const int m = (g * MB + mb) * 32 + (lane & 31);
     const int cl = 2 * cp + (lane >> 5);
-    const bool valid = m < p.M && cl < c[2];
-    const long long woff = p.src[s].off0 + (long long)m * p.src[s].sm + (long long)(c[1] + cl) * p.src[s].sc +
+    const bool valid = m >= p.row_base && m < p.M && cl < c[2];
+    const long long woff = p.src[s].off0 + (long long)(m - p.row_base) * p.src[s].sm + (long long)(c[1] + cl) * p.src[s].sc +
                            (long long)(lo + tapi) * p.src[s].st;
     float* ap = p.a + ((long long)e[2] + rec) * (MB * 64) + mb * 64 + lane;
     if (p.unpack) {
@@ -816,8 +823,10 @@ static int launch_pack(const int32_t* plan_dev, const int32_t* plan_host, int pl
                        const char* who, void* stream) {
   if (int rc = fst_check_plan(plan_host, plan_len, p0.M, who)) return rc;
   const PlanView pv = plan_view(plan_host);
+  FST_REQUIRE(p0.g_begin >= 0 && p0.g_begin < p0.g_end && p0.g_end <= pv.n_mgroups && p0.row_base >= 0,
+              "%s: bad M-group range [%d,%d) of %d", who, p0.g_begin, p0.g_end, pv.n_mgroups);
   long long max_elems = 0;
-  for (int gq = 0; gq < pv.n_chunks * pv.n_mgroups; ++gq) {
+  for (int gq = p0.g_begin * pv.n_chunks; gq < p0.g_end * pv.n_chunks; ++gq) {
     const int32_t* e = pv.mg + 4 * gq;
     const int32_t* c = pv.chunk + 4 * (gq % pv.n_chunks);
     if (e[1] > e[0]) {
@@ -830,19 +839,21 @@ static int launch_pack(const int32_t* plan_dev, const int32_t* plan_host, int pl
   if (bx > 1024) bx = 1024;
   PackParams p = p0;
   p.plan = plan_dev;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)(pv.n_chunks * pv.n_mgroups)), dim3(256), 0,
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)(pv.n_chunks * (p0.g_end - p0.g_begin))), dim3(256), 0,
                      (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int fst_pack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
-                                const fst_wsrc* src0, const fst_wsrc* src1, int M, float* a_packed, void* stream) {
-  FST_REQUIRE(plan_dev && src0 && src0->w && a_packed, "fst_pack_weights: null operand");
+                                const fst_wsrc* src0, const fst_wsrc* src1, int M, int g_begin, int g_end, int row_base,
+                                float* a_packed, void* stream) {
+  FST_REQUIRE(plan_dev && plan_host && src0 && src0->w && a_packed, "fst_pack_weights: null operand");
   PackParams p = {};
   p.src[0] = *src0;
   if (src1) p.src[1] = *src1;
   p.a = a_packed; p.M = M; p.unpack = 0;
+  p.g_begin = g_begin; p.g_end = g_end < 0 ? (plan_len >= FST_PLAN_HDR ? plan_host[1] : 0) : g_end; p.row_base = row_base;
   const PlanView pv = plan_view(plan_host);
   if (plan_len >= FST_PLAN_HDR)
     for (int q = 0; q < pv.n_chunks; ++q)
@@ -859,6 +870,7 @@ extern "C" int fst_unpack_weights(const int32_t* plan_dev, const int32_t* plan_h
   p.src[1] = {nullptr, off0_1, sm1, sc1, st1};
   p.dst[0] = dw0; p.dst[1] = dw1;
   p.a = const_cast<float*>(a_packed); p.M = M; p.unpack = 1;
+  p.g_begin = 0; p.g_end = (plan_host && plan_len >= FST_PLAN_HDR) ? plan_host[1] : 0; p.row_base = 0;
   const PlanView pv = plan_view(plan_host);
   if (plan_len >= FST_PLAN_HDR)
     for (int q = 0; q < pv.n_chunks; ++q)

@@ -25,7 +25,8 @@ class KernelTimer:
     """HIP-event timing of the conv-engine launches on the launch stream (used by bench.py's roofline leg).
     Keyed by the kernel template a launch dispatches to, so totals line up with rocprofv3's per-kernel stats."""
 
-    def __init__(self):
+    def __init__(self, detail: bool = False):
+        self.detail = detail       # True: key launches by shape as well (diagnostics)
         self.records = {}          # key -> list of (start_event, end_event, algorithmic_flops)
 
     def begin(self):
@@ -121,26 +122,35 @@ class pack_cache:
 
 
 def pack_weights(plan: Plan, M: int, w0: Tensor, s0: Tuple[int, int, int, int], w1: Optional[Tensor] = None,
-                 s1: Tuple[int, int, int, int] = (0, 0, 0, 0)) -> Tensor:
+                 s1: Tuple[int, int, int, int] = (0, 0, 0, 0), parts=None) -> Tensor:
+    """Pack weights for ``plan``.  ``parts`` (optional) fills different M-group ranges from different weight
+    tensors: a list of (g_begin, g_end, row_base, row_end, w, strides)."""
     if _PACK_CACHE is not None:
-        key = (id(plan), M, w0.data_ptr(), w0._version, s0, None if w1 is None else (w1.data_ptr(), w1._version), s1)
+        key = (id(plan), M, w0.data_ptr(), w0._version, s0, None if w1 is None else (w1.data_ptr(), w1._version), s1,
+               None if parts is None else tuple((p[0], p[1], p[2], p[3], p[4].data_ptr(), p[4]._version, p[5]) for p in parts))
         hit = _PACK_CACHE.get(key)
         if hit is not None:
             return hit[0]
-        a = _pack_weights(plan, M, w0, s0, w1, s1)
-        _PACK_CACHE[key] = (a, w0, w1, plan)
+        a = _pack_weights(plan, M, w0, s0, w1, s1, parts)
+        _PACK_CACHE[key] = (a, w0, w1, plan, parts)
         return a
-    return _pack_weights(plan, M, w0, s0, w1, s1)
+    return _pack_weights(plan, M, w0, s0, w1, s1, parts)
 
 
-def _pack_weights(plan: Plan, M: int, w0: Tensor, s0, w1: Optional[Tensor], s1) -> Tensor:
+def _pack_weights(plan: Plan, M: int, w0: Tensor, s0, w1: Optional[Tensor], s1, parts=None) -> Tensor:
     lib = _lib.load()
     a = torch.empty(plan.packed_floats, device=w0.device, dtype=torch.float32)
-    src0 = _wsrc(w0, *s0)
-    src1 = _wsrc(w1, *s1) if w1 is not None else None
-    check(lib.fst_pack_weights(ptr(plan.dev(w0.device)), plan.host_ptr(), plan.length, ctypes.byref(src0),
-                               ctypes.byref(src1) if src1 is not None else None, M, ptr(a), stream_ptr()),
-          "fst_pack_weights")
+    second = (w1, s1)
+    if parts is None:
+        parts = [(0, -1, 0, M, w0, s0)]
+    else:
+        second = (None, (0, 0, 0, 0))
+    for (g0, g1, row_base, row_end, w, sw) in parts:
+        src0 = _wsrc(w, *sw)
+        src1 = _wsrc(second[0], *second[1]) if second[0] is not None else None
+        check(lib.fst_pack_weights(ptr(plan.dev(w0.device)), plan.host_ptr(), plan.length, ctypes.byref(src0),
+                                   ctypes.byref(src1) if src1 is not None else None, row_end, g0, g1, row_base, ptr(a),
+                                   stream_ptr()), "fst_pack_weights")
     return a
 
 
@@ -152,9 +162,10 @@ def unpack_weights(plan: Plan, M: int, a: Tensor, dw0: Tensor, s0, dw1: Optional
 
 def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Optional[Tensor], B: int, L: int, M: int,
               y: Optional[Tensor], res: Optional[Tensor] = None, y2: Optional[Tensor] = None, msplit: Optional[int] = None,
-              nb: int = 1, ksplit: int = 1, flags: int = 0) -> None:
+              nb: int = 1, ksplit: int = 1, flags: int = 0, m2_start: Optional[int] = None) -> None:
     lib = _lib.load()
     msplit = M if msplit is None else msplit
+    m2_start = msplit if m2_start is None else m2_start
     x0_bs, _ = _ncl(x0, "x0")
     x1_bs = _ncl(x1, "x1")[0] if x1 is not None else 0
     y_bs = _ncl(y, "y")[0] if y is not None else 0
@@ -162,11 +173,14 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
     y2_bs = _ncl(y2, "y2")[0] if y2 is not None else 0
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     check(lib.fst_conv_gemm(ptr(x0), x0_bs, ptr(x1), x1_bs, ptr(a), ptr(plan.dev(x0.device)), plan.host_ptr(),
-                            plan.length, ptr(bias), ptr(y), y_bs, ptr(res), res_bs, ptr(y2), y2_bs, msplit, B, L, M,
-                            nb, ksplit, flags, stream_ptr()), "fst_conv_gemm")
+                            plan.length, ptr(bias), ptr(y), y_bs, ptr(res), res_bs, ptr(y2), y2_bs, msplit, m2_start, B, L,
+                            M, nb, ksplit, flags, stream_ptr()), "fst_conv_gemm")
     if t0 is not None:
         name = "conv_gemm_pipe_kernel" if (plan.pipeable and nb <= 2) else "conv_gemm_kernel"
-        KERNEL_TIMER.end(f"{name}<{plan.MB}, {nb}>", t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
+        key = f"{name}<{plan.MB}, {nb}>"
+        if KERNEL_TIMER.detail:
+            key += f" M={M} rec={plan.total_records} dil={plan.dil}"
+        KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
 
 
 def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor], msplit: int, B: int,
@@ -183,8 +197,10 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
           "fst_conv_wgrad")
     if t0 is not None:
         wide = bool(((plan.entries()[:, :, 1] - plan.entries()[:, :, 0]) > 1).any())
-        KERNEL_TIMER.end(f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}>", t0,
-                         2.0 * B * L * _plan_macs_per_step(plan, M))
+        key = f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}>"
+        if KERNEL_TIMER.detail:
+            key += f" M={M} rec={plan.total_records} ksplit={ksplit}"
+        KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
     return da
 
 
@@ -343,6 +359,35 @@ class ConvSpec:
         if out is None:
             out = torch.empty(B, self.C0, L, device=dy.device, dtype=torch.float32)
         conv_gemm(plan, a, dy, None, None, B, L, self.C0, out, res, nb=nb, flags=flags)
+        return out
+
+    def dx01_plan(self, nb: int) -> Plan:
+        """Fused data gradient of both inputs: rows [0, C0) = d x0 (all taps, flipped); rows [R, R+C1) = d x1
+        (the zero-offset tap only), R = C0 rounded up to an M-group — one pass over dy instead of two."""
+        key = ("dx01", nb)
+        if key not in self._plans:
+            mb = pick_mb(self.C0)
+            R = ((self.C0 + mb * 32 - 1) // (mb * 32)) * (mb * 32)
+            tf = self.ntaps - 1 - self.x1_tap
+            live = [(0, self.ntaps)] * R + [(tf, tf + 1)] * self.C1
+            self._plans[key] = build_plan(R + self.C1, [Segment(0, self.M, 0, self.ntaps)], self.ntaps, self.dil,
+                                          self._halo() - self.pad_left, MB=mb, chunk_c=PIPE_C, split_taps=True,
+                                          row_live=live)
+        return self._plans[key]
+
+    def grad_x01(self, dy: Tensor, w0: Tensor, w1: Tensor, res0: Optional[Tensor], acc1: Tensor) -> Tensor:
+        """returns d x0 = res0 + conv_T(dy, w0);  acc1 += conv_T(dy, w1)  — one launch."""
+        B, L = dy.size(0), dy.size(2)
+        mb = pick_mb(self.C0)
+        nb = self.nb_for(B, L, mb, 0, 0)
+        plan = self.dx01_plan(nb)
+        R = plan.M - self.C1
+        n_g0 = R // (mb * 32)
+        a = pack_weights(plan, plan.M, w0, self.s_w0_T(), parts=[(0, n_g0, 0, self.C0, w0, self.s_w0_T()),
+                                                                 (n_g0, plan.n_mgroups, R, plan.M, w1, self.s_w1_T())])
+        out = torch.empty(B, self.C0, L, device=dy.device, dtype=torch.float32)
+        conv_gemm(plan, a, dy, None, None, B, L, plan.M, out, res0, acc1, msplit=self.C0, nb=nb, flags=EPI_ACC2,
+                  m2_start=R)
         return out
 
     def grad_x1(self, dy: Tensor, w1: Tensor, out: Optional[Tensor] = None, flags: int = 0) -> Tensor:
@@ -599,8 +644,7 @@ class WNFn(torch.autograd.Function):
                 d_in_b[i] = row_sum(dg)
                 d_cond_b[i] = d_in_b[i]
             # ---- into the layer input (residual path + dilated conv) and into the conditioning input
-            d_a = S.ins[i].grad_x0(dg, in_w[i], res=d_a)
-            S.ins[i].grad_x1(dg, cond_w[2 * n * i: 2 * n * (i + 1)], out=d_u0, flags=EPI_ACC1)
+            d_a = S.ins[i].grad_x01(dg, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], d_a, d_u0)
         S.start.grad_x0(d_a, start_w, out=d_u0, flags=EPI_ACC1)
         d_start_w = d_start_b = None
         if need_w:

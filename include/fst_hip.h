@@ -56,7 +56,8 @@ typedef struct {
  * F.conv1d at OS_CNN/OS_CNN.py:71, Simplified_NF_WaveGlow.py:36,41,103,107,112,116,123. */
 int fst_pack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
                      const fst_wsrc* src0_host, const fst_wsrc* src1_host,
-                     int M, float* a_packed, void* stream);
+                     int M, int g_begin, int g_end /* M-group range, -1 = all */, int row_base /* view row = m - row_base */,
+                     float* a_packed, void* stream);
 
 /* Inverse of fst_pack_weights for weight gradients: scatter a packed gradient back to PyTorch
  * layout (dw0/dw1 must be zero-filled by the caller when the plan does not cover every tap). */
@@ -71,8 +72,8 @@ int fst_unpack_weights(const int32_t* plan_dev, const int32_t* plan_host, int pl
 int fst_mask_taps(float* w, const int32_t* live_lo, const int32_t* live_hi, int M, int C, int K, void* stream);
 
 /* y[b,m,t] = bias[m] + Σ_k A[m,k]·xcol[b,k,t]  — the forward engine (f32 MFMA, LDS-staged input
- * window).  Rows m < msplit go to y (+res if given); rows ≥ msplit go to y2 (accumulated if
- * FST_EPI_ACC2).  Replaces F.conv1d/nn.Conv1d at OS_CNN/OS_CNN.py:71,164 and
+ * window).  Rows m < msplit go to y (+res if given); rows ≥ m2_start go to y2[m − m2_start]
+ * (accumulated if FST_EPI_ACC2).  Replaces F.conv1d/nn.Conv1d at OS_CNN/OS_CNN.py:71,164 and
  * Simplified_NF_WaveGlow.py:36,41,103,107,112,116,123; with transposed packing it is also the
  * data-gradient conv of every one of those.
  *   flags: FST_EPI_RELU, FST_EPI_ACC2, FST_EPI_ATOMIC (ksplit>1; y must be pre-initialised) */
@@ -84,7 +85,7 @@ int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs
                   const float* a_packed, const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
                   const float* bias,
                   float* y, int64_t y_bs, const float* res, int64_t res_bs,
-                  float* y2, int64_t y2_bs, int msplit,
+                  float* y2, int64_t y2_bs, int msplit, int m2_start /* rows [msplit, m2_start) are padding */,
                   int B, int L, int M, int nb_cfg, int ksplit, int flags, void* stream);
 
 /* dA_packed[(g,q) records] += Σ_{b,t} dy[b,m,t]·xcol[b,k,t]  — weight-gradient engine (f32 MFMA,

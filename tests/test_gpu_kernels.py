@@ -66,6 +66,12 @@ def test_conv_forward_backward(M, C0, ntaps, dil, pad_left, C1, B, L):
     assert_close(dx0, x0.grad, 2e-5, "dx0")
     if C1:
         assert_close(spec.grad_x1(f(dy), f(w1)), x1.grad, 2e-5, "dx1")
+        res0 = torch.randn(B, C0, L, generator=g)                  # fused: dx0 = res0 + ..., acc1 += ...
+        acc1 = torch.randn(B, C1, L, generator=g)
+        acc1_d = acc1.to(DEV).clone()
+        fused = spec.grad_x01(f(dy), f(w0), f(w1), res0.to(DEV), acc1_d)
+        assert_close(fused, res0.double() + x0.grad, 2e-5, "fused dx0")
+        assert_close(acc1_d, acc1.double() + x1.grad, 2e-5, "fused dx1")
     dw0, dw1 = spec.grad_w(f(x0), f(x1), f(dy))
     assert_close(dw0, w0.grad, 1e-4, "dw0")
     if C1:
