@@ -36,6 +36,88 @@ struct ConvGemmParams {
   int tiles_per_seq, ksplit, flags, mg_per_wg, ldw;
 };
 
+// Epilogue shared by both forward kernels.  C/D layout of the 32x32 MFMA: col = lane&31 (time),
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  All loads of one 32-row block (residual / accumulate operands) are
+// issued before any store of that block: the output may alias them, so interleaving would serialise one
+// load→add→store chain per element on memory latency.
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue_block(const ConvGemmParams& p, f32x16 (&accb)[NB], int mb, int g, int b,
+                                                    int t0, int wave_n0, int half, int l31, bool add_bias) {
+  const int L = p.L;
+  // addresses = wave-uniform row base (SGPRs) + ONE per-lane offset: rows r and r+4 of a register pair differ by
+  // the lane half, time by the lane
+  const int vo = half * 4 * L + wave_n0 + l31;
+  const bool plain = !(p.flags & FST_EPI_ATOMIC);
+#pragma unroll
+  for (int rh = 0; rh < 16; rh += 8) {                 // batches of 8 registers keep the footprint small
+    float extra[8][NB];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = rh + rr;
+      const int m_lo = (g * MB + mb) * 32 + (r & 3) + 8 * (r >> 2);   // wave-uniform; this lane's row is m_lo + 4*half
+      const int m = m_lo + 4 * half;
+      const bool first = m < p.msplit, second = m >= p.m2_start && m < p.M;
+      const float bias_v = (add_bias && (first || second)) ? p.bias[m] : 0.f;
+      const float* res_row = p.res ? p.res + ((long long)b * p.res_bs + (long long)m_lo * L + t0) : nullptr;
+      const float* y_row = p.y ? p.y + ((long long)b * p.y_bs + (long long)m_lo * L + t0) : nullptr;
+      const float* y2_row = p.y2 ? p.y2 + ((long long)b * p.y2_bs + (long long)(m_lo - p.m2_start) * L + t0) : nullptr;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bool t_ok = t0 + wave_n0 + nb * 32 + l31 < L;
+        float e = bias_v;
+        if (t_ok && plain) {
+          if (first) {
+            if (res_row) e += res_row[vo + nb * 32];
+            if (p.flags & FST_EPI_ACC1) e += y_row[vo + nb * 32];
+          } else if (second) {
+            if (p.flags & FST_EPI_ACC2) e += y2_row[vo + nb * 32];
+          }
+        }
+        extra[rr][nb] = e;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = rh + rr;
+      const int m_lo = (g * MB + mb) * 32 + (r & 3) + 8 * (r >> 2);
+      const int m = m_lo + 4 * half;
+      const bool first = m < p.msplit, second = m >= p.m2_start && m < p.M;
+      if (first || second) {
+        float* y_row = p.y ? p.y + ((long long)b * p.y_bs + (long long)m_lo * L + t0) : nullptr;
+        float* y2_row = p.y2 ? p.y2 + ((long long)b * p.y2_bs + (long long)(m_lo - p.m2_start) * L + t0) : nullptr;
+        float* dst = first ? y_row : y2_row;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          if (t0 + wave_n0 + nb * 32 + l31 < L) {
+            float v = accb[nb][r] + extra[rr][nb];
+            if (!plain) {
+              atomicAdd(dst + vo + nb * 32, v);
+            } else {
+              if (p.flags & FST_EPI_RELU) v = fmaxf(v, 0.f);
+              dst[vo + nb * 32] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Epilogue shared by both forward kernels.  C/D layout of the 32x32 MFMA: col = lane&31 (time),
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The loads of 8 accumulator registers (residual / accumulate operands) are
+// issued before any of their stores: the output may alias them, so interleaving would serialise one
+// load→add→store chain per element on memory latency.  Blocks are expanded by hand so every accumulator index
+// is a compile-time constant (a runtime index would send the accumulators to scratch).
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&acc)[MB][NB], int g, int b, int t0,
+                                              int wave_n0, int half, int l31, bool add_bias) {
+#define FST_EPI_BLOCK(I) \
+  if constexpr (MB > I) conv_epilogue_block<MB, NB>(p, acc[I], I, g, b, t0, wave_n0, half, l31, add_bias);
+  FST_EPI_BLOCK(0) FST_EPI_BLOCK(1) FST_EPI_BLOCK(2) FST_EPI_BLOCK(3)
+  FST_EPI_BLOCK(4) FST_EPI_BLOCK(5) FST_EPI_BLOCK(6) FST_EPI_BLOCK(7)
+#undef FST_EPI_BLOCK
+}
+
 template <int MB, int NB>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -129,44 +211,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
       }
     }
 
-    // epilogue: C/D layout of 32x32 MFMA — col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool add_bias = p.bias != nullptr && blockIdx.z == 0;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (g * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= p.M) continue;
-        const float bias_v = add_bias ? p.bias[m] : 0.f;
-        float* dst;
-        const float* resp = nullptr;
-        bool accum;
-        if (m < p.msplit) {
-          dst = p.y + (long long)b * p.y_bs + (long long)m * L;
-          if (p.res) resp = p.res + (long long)b * p.res_bs + (long long)m * L;
-          accum = (p.flags & FST_EPI_ACC1) != 0;
-        } else if (m >= p.m2_start) {
-          dst = p.y2 + (long long)b * p.y2_bs + (long long)(m - p.m2_start) * L;
-          accum = (p.flags & FST_EPI_ACC2) != 0;
-        } else {
-          continue;   // padding rows between the two outputs
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-          const int t = t0 + wave_n0 + nb * 32 + l31;
-          if (t >= L) continue;
-          float v = acc[mb][nb][r] + bias_v;
-          if (p.flags & FST_EPI_ATOMIC) {
-            atomicAdd(dst + t, v);
-          } else {
-            if (resp) v += resp[t];
-            if (accum) v += dst[t];
-            if (p.flags & FST_EPI_RELU) v = fmaxf(v, 0.f);
-            dst[t] = v;
-          }
-        }
-      }
-    }
+    conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0);
   }
 }
 
@@ -288,43 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p
     buf ^= 1;
   }
 
-  const bool add_bias = p.bias != nullptr && blockIdx.z == 0;
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (g * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (m >= p.M) continue;
-      const float bias_v = add_bias ? p.bias[m] : 0.f;
-      float* dst;
-      const float* resp = nullptr;
-      bool accum;
-      if (m < p.msplit) {
-        dst = p.y + (long long)b * p.y_bs + (long long)m * L;
-        if (p.res) resp = p.res + (long long)b * p.res_bs + (long long)m * L;
-        accum = (p.flags & FST_EPI_ACC1) != 0;
-      } else if (m >= p.m2_start) {
-        dst = p.y2 + (long long)b * p.y2_bs + (long long)(m - p.m2_start) * L;
-        accum = (p.flags & FST_EPI_ACC2) != 0;
-      } else {
-        continue;   // padding rows between the two outputs
-      }
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int t = t0 + wave_n0 + nb * 32 + l31;
-        if (t >= L) continue;
-        float v = acc[mb][nb][r] + bias_v;
-        if (p.flags & FST_EPI_ATOMIC) {
-          atomicAdd(dst + t, v);
-        } else {
-          if (resp) v += resp[t];
-          if (accum) v += dst[t];
-          if (p.flags & FST_EPI_RELU) v = fmaxf(v, 0.f);
-          dst[t] = v;
-        }
-      }
-    }
-  }
+  conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0);
 }
 
 static bool plan_is_pipeable(const PlanView& pv) {
@@ -659,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     if (tile + 1 < tile_end) fetch(tile + 1);
 
     const float* bbase = dyt + (wave * CB * 32 + l31) * DYS + half;
-#pragma unroll 1
+#pragma unroll 2
     for (int tau = 0; tau < TW; tau += 2) {
       float av[WG_ITEMS], bv[CB];
 #pragma unroll
