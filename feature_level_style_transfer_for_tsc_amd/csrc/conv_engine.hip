@@ -15,6 +15,7 @@
 //             strides → conflict-free), accumulators are written with fp32 atomics whose lanes cover
 //             two 128-B segments (the full-rate shape, MI355X_MICROARCH "Global float atomics").
 #include "fst_common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient
@@ -40,40 +41,43 @@ struct ConvGemmParams {
 // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  All loads of one 32-row block (residual / accumulate operands) are
 // issued before any store of that block: the output may alias them, so interleaving would serialise one
 // load→add→store chain per element on memory latency.
-template <int MB, int NB>
+// Epilogue of one 32-row block.  C/D layout of the 32x32 MFMA: col = lane&31 (time), row = (r&3) + 8*(r>>2) +
+// 4*(lane>>5).  MODE 0: plain store; 1: store with residual / accumulate operands; 2: fp32 atomics (K split).
+// MODE 1 is written branch-free: every operand load is unconditional — a lane that needs no operand reads a
+// fixed safe address instead — so hipcc issues the 8×NB×2 loads of a batch back to back and waits once.  (With
+// predicated loads it emits one exec-mask branch and one s_waitcnt vmcnt(0) PER LOAD: the res_skip forward then
+// runs at a quarter of the speed.)  Addresses are a wave-uniform row base plus ONE per-lane offset.
+template <int MB, int NB, int MODE>
 __device__ __forceinline__ void conv_epilogue_block(const ConvGemmParams& p, f32x16 (&accb)[NB], int mb, int g, int b,
                                                     int t0, int wave_n0, int half, int l31, bool add_bias) {
   const int L = p.L;
-  // addresses = wave-uniform row base (SGPRs) + ONE per-lane offset: rows r and r+4 of a register pair differ by
-  // the lane half, time by the lane
   const int vo = half * 4 * L + wave_n0 + l31;
-  const bool plain = !(p.flags & FST_EPI_ATOMIC);
+  const float* safe = p.y2 ? p.y2 : p.y;
+  const bool has_res = p.res != nullptr, acc1 = (p.flags & FST_EPI_ACC1) != 0, acc2 = (p.flags & FST_EPI_ACC2) != 0;
 #pragma unroll
-  for (int rh = 0; rh < 16; rh += 8) {                 // batches of 8 registers keep the footprint small
-    float extra[8][NB];
+  for (int rh = 0; rh < 16; rh += 8) {                 // batches of 8 accumulator registers
+    float ea[8][NB], eb[8][NB];
+    if (MODE == 1) {
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = rh + rr;
-      const int m_lo = (g * MB + mb) * 32 + (r & 3) + 8 * (r >> 2);   // wave-uniform; this lane's row is m_lo + 4*half
-      const int m = m_lo + 4 * half;
-      const bool first = m < p.msplit, second = m >= p.m2_start && m < p.M;
-      const float bias_v = (add_bias && (first || second)) ? p.bias[m] : 0.f;
-      const float* res_row = p.res ? p.res + ((long long)b * p.res_bs + (long long)m_lo * L + t0) : nullptr;
-      const float* y_row = p.y ? p.y + ((long long)b * p.y_bs + (long long)m_lo * L + t0) : nullptr;
-      const float* y2_row = p.y2 ? p.y2 + ((long long)b * p.y2_bs + (long long)(m_lo - p.m2_start) * L + t0) : nullptr;
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = rh + rr;
+        const int m_lo = (g * MB + mb) * 32 + (r & 3) + 8 * (r >> 2);   // wave-uniform; this lane's row is m_lo + 4*half
+        const int m = m_lo + 4 * half;
+        const bool first = m < p.msplit, second = m >= p.m2_start && m < p.M;
+        const float* res_row = p.res + ((long long)b * p.res_bs + (long long)m_lo * L + t0);
+        const float* y_row = p.y + ((long long)b * p.y_bs + (long long)m_lo * L + t0);
+        const float* y2_row = p.y2 + ((long long)b * p.y2_bs + (long long)(m_lo - p.m2_start) * L + t0);
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const bool t_ok = t0 + wave_n0 + nb * 32 + l31 < L;
-        float e = bias_v;
-        if (t_ok && plain) {
-          if (first) {
-            if (res_row) e += res_row[vo + nb * 32];
-            if (p.flags & FST_EPI_ACC1) e += y_row[vo + nb * 32];
-          } else if (second) {
-            if (p.flags & FST_EPI_ACC2) e += y2_row[vo + nb * 32];
-          }
+        for (int nb = 0; nb < NB; ++nb) {
+          const bool t_ok = t0 + wave_n0 + nb * 32 + l31 < L;
+          const bool use_a = t_ok && first && has_res;
+          const bool use_b = t_ok && ((first && acc1) || (second && acc2));
+          const float* pa = use_a ? res_row + vo + nb * 32 : safe;
+          const float* pb = use_b ? (first ? y_row : y2_row) + vo + nb * 32 : safe;
+          const float va = *pa, vb = *pb;
+          ea[rr][nb] = use_a ? va : 0.f;
+          eb[rr][nb] = use_b ? vb : 0.f;
         }
-        extra[rr][nb] = e;
       }
     }
 #pragma unroll
@@ -83,14 +87,15 @@ __device__ __forceinline__ void conv_epilogue_block(const ConvGemmParams& p, f32
       const int m = m_lo + 4 * half;
       const bool first = m < p.msplit, second = m >= p.m2_start && m < p.M;
       if (first || second) {
-        float* y_row = p.y ? p.y + ((long long)b * p.y_bs + (long long)m_lo * L + t0) : nullptr;
-        float* y2_row = p.y2 ? p.y2 + ((long long)b * p.y2_bs + (long long)(m_lo - p.m2_start) * L + t0) : nullptr;
-        float* dst = first ? y_row : y2_row;
+        const float bias_v = add_bias ? p.bias[m] : 0.f;
+        float* dst = first ? p.y + ((long long)b * p.y_bs + (long long)m_lo * L + t0)
+                           : p.y2 + ((long long)b * p.y2_bs + (long long)(m_lo - p.m2_start) * L + t0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           if (t0 + wave_n0 + nb * 32 + l31 < L) {
-            float v = accb[nb][r] + extra[rr][nb];
-            if (!plain) {
+            float v = accb[nb][r] + bias_v;
+            if (MODE == 1) v += ea[rr][nb] + eb[rr][nb];
+            if (MODE == 2) {
               atomicAdd(dst + vo + nb * 32, v);
             } else {
               if (p.flags & FST_EPI_RELU) v = fmaxf(v, 0.f);
@@ -103,19 +108,27 @@ __device__ __forceinline__ void conv_epilogue_block(const ConvGemmParams& p, f32
   }
 }
 
-// Epilogue shared by both forward kernels.  C/D layout of the 32x32 MFMA: col = lane&31 (time),
-// row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The loads of 8 accumulator registers (residual / accumulate operands) are
-// issued before any of their stores: the output may alias them, so interleaving would serialise one
-// load→add→store chain per element on memory latency.  Blocks are expanded by hand so every accumulator index
-// is a compile-time constant (a runtime index would send the accumulators to scratch).
-template <int MB, int NB>
-__device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&acc)[MB][NB], int g, int b, int t0,
-                                              int wave_n0, int half, int l31, bool add_bias) {
+// Blocks are expanded by hand so every accumulator index is a compile-time constant (a runtime index would send
+// the accumulators to scratch).
+template <int MB, int NB, int MODE>
+__device__ __forceinline__ void conv_epilogue_mode(const ConvGemmParams& p, f32x16 (&acc)[MB][NB], int g, int b, int t0,
+                                                   int wave_n0, int half, int l31, bool add_bias) {
 #define FST_EPI_BLOCK(I) \
-  if constexpr (MB > I) conv_epilogue_block<MB, NB>(p, acc[I], I, g, b, t0, wave_n0, half, l31, add_bias);
+  if constexpr (MB > I) conv_epilogue_block<MB, NB, MODE>(p, acc[I], I, g, b, t0, wave_n0, half, l31, add_bias);
   FST_EPI_BLOCK(0) FST_EPI_BLOCK(1) FST_EPI_BLOCK(2) FST_EPI_BLOCK(3)
   FST_EPI_BLOCK(4) FST_EPI_BLOCK(5) FST_EPI_BLOCK(6) FST_EPI_BLOCK(7)
 #undef FST_EPI_BLOCK
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&acc)[MB][NB], int g, int b, int t0,
+                                              int wave_n0, int half, int l31, bool add_bias) {
+  if (p.flags & FST_EPI_ATOMIC)
+    conv_epilogue_mode<MB, NB, 2>(p, acc, g, b, t0, wave_n0, half, l31, add_bias);
+  else if (p.res != nullptr || (p.flags & (FST_EPI_ACC1 | FST_EPI_ACC2)))
+    conv_epilogue_mode<MB, NB, 1>(p, acc, g, b, t0, wave_n0, half, l31, add_bias);
+  else
+    conv_epilogue_mode<MB, NB, 0>(p, acc, g, b, t0, wave_n0, half, l31, add_bias);
 }
 
 template <int MB, int NB>
@@ -668,21 +681,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     if (tile + 1 < tile_end) fetch(tile + 1);
 
     const float* bbase = dyt + (wave * CB * 32 + l31) * DYS + half;
-#pragma unroll 2
-    for (int tau = 0; tau < TW; tau += 2) {
-      float av[WG_ITEMS], bv[CB];
+    // straight-line k-steps for the live item count (no scalar branches between MFMAs)
+    auto ksteps = [&](auto nit_c) {
+      constexpr int NIT = decltype(nit_c)::value;
+#pragma unroll 1
+      for (int tau = 0; tau < TW; tau += 2) {
+        float av[NIT], bv[CB];
 #pragma unroll
-      for (int i = 0; i < WG_ITEMS; ++i) av[i] = lds[rowoff[i] + tau + half];
+        for (int i = 0; i < NIT; ++i) av[i] = lds[rowoff[i] + tau + half];
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) bv[cb] = bbase[cb * 32 * DYS + tau];
+        for (int cb = 0; cb < CB; ++cb) bv[cb] = bbase[cb * 32 * DYS + tau];
 #pragma unroll
-      for (int i = 0; i < WG_ITEMS; ++i) {
-        if (i < nit) {
+        for (int i = 0; i < NIT; ++i)
 #pragma unroll
           for (int cb = 0; cb < CB; ++cb)
             acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[cb], acc[i][cb], 0, 0, 0);
-        }
       }
+    };
+    switch (nit) {
+      case 1: ksteps(std::integral_constant<int, 1>{}); break;
+      case 2: ksteps(std::integral_constant<int, 2>{}); break;
+      case 3: ksteps(std::integral_constant<int, 3>{}); break;
+      default: ksteps(std::integral_constant<int, 4>{}); break;
     }
   }
 
