@@ -681,28 +681,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p) {
     if (tile + 1 < tile_end) fetch(tile + 1);
 
     const float* bbase = dyt + (wave * CB * 32 + l31) * DYS + half;
-    // straight-line k-steps for the live item count (no scalar branches between MFMAs)
-    auto ksteps = [&](auto nit_c) {
-      constexpr int NIT = decltype(nit_c)::value;
-#pragma unroll 1
-      for (int tau = 0; tau < TW; tau += 2) {
-        float av[NIT], bv[CB];
+    // straight-line k-steps: padding items multiply the zero row instead of branching around their MFMAs (all
+    // workgroups of a launch are co-resident, so the launch lasts as long as a full workgroup either way)
+#pragma unroll 2
+    for (int tau = 0; tau < TW; tau += 2) {
+      float av[WG_ITEMS], bv[CB];
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) av[i] = lds[rowoff[i] + tau + half];
+      for (int i = 0; i < WG_ITEMS; ++i) av[i] = lds[rowoff[i] + tau + half];
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) bv[cb] = bbase[cb * 32 * DYS + tau];
+      for (int cb = 0; cb < CB; ++cb) bv[cb] = bbase[cb * 32 * DYS + tau];
 #pragma unroll
-        for (int i = 0; i < NIT; ++i)
+      for (int i = 0; i < WG_ITEMS; ++i)
 #pragma unroll
-          for (int cb = 0; cb < CB; ++cb)
-            acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[cb], acc[i][cb], 0, 0, 0);
-      }
-    };
-    switch (nit) {
-      case 1: ksteps(std::integral_constant<int, 1>{}); break;
-      case 2: ksteps(std::integral_constant<int, 2>{}); break;
-      case 3: ksteps(std::integral_constant<int, 3>{}); break;
-      default: ksteps(std::integral_constant<int, 4>{}); break;
+        for (int cb = 0; cb < CB; ++cb)
+          acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[cb], acc[i][cb], 0, 0, 0);
     }
   }
 
