@@ -39,6 +39,8 @@ def cpu_baseline(L: int, pairs: int, steps: int):
     """The CPU oracle (oracle/restatement.py, a port of the reference's step) timed on this host's cores on a
     bounded sample of the same workload.  Baseline only — never the product path."""
     from oracle import restatement as R
+    # the GPU box gives one GPU a 16-CPU share; torch's default (all visible cores) oversubscribes it 8x
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     torch.manual_seed(1234)
     js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=1234)
     g = torch.Generator().manual_seed(99)

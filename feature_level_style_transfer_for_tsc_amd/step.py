@@ -225,39 +225,53 @@ class JointTrainer:
         return self._step_body(x_t, y_t, x_s, y_s, epoch, t_samples, ratios)
 
     def _step_body(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
-        """Everything device-side and shape-static, so it runs eagerly or under hipGraph capture unchanged."""
-        with ops.pack_cache(), self.m["nf"].shared_fold():
-            return self._step_impl(x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios)
+        """Everything device-side and shape-static, so it runs eagerly or under hipGraph capture unchanged.
+        Two halves with the step's only collectives between them (so a captured step never contains RCCL):
+        A = forward, GradNorm partial backwards, full backward;  B = GradNorm weight update + optimisers."""
+        mid = self._step_part_a(x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios)
+        self._reduce(mid)
+        return self._step_part_b(mid)
 
-    def _step_impl(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
-        L, aux = self.forward_losses(x_t, y_t, x_s, y_s, t_samples, noise_ratios)
-        lt = torch.stack([L["nf_t"], L["ce_t"]])
-        ls = torch.stack([L["nf_s"], L["ce_s"], L["ce_s2t2s"]])
-        lt_v, ls_v = lt.detach(), ls.detach()
-        if self.bucket is not None:                                           # keep GradNorm identical on all ranks
-            lt_v, ls_v = self.bucket.mean_scalars(lt_v), self.bucket.mean_scalars(ls_v)
+    def _step_part_a(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
+        with ops.pack_cache(), self.m["nf"].shared_fold():
+            L, aux = self.forward_losses(x_t, y_t, x_s, y_s, t_samples, noise_ratios)
+            lt = torch.stack([L["nf_t"], L["ce_t"]])
+            ls = torch.stack([L["nf_s"], L["ce_s"], L["ce_s2t2s"]])
+            a, b, c, d = loss_coefficients(epoch)
+            # Q3: first backward + second backward (weights zeroed) == Σ wᵢ∇Lᵢ + 2·(a∇cdan + b∇fd + c∇sl_t + d∇sl_s)
+            total = torch.sum(self.w_t.detach() * lt) + torch.sum(self.w_s.detach() * ls) \
+                + 2.0 * (a * L["cdan"] + b * L["fd_s"] + c * L["sl_t"] + d * L["sl_s"])
+            for o in self.opts.values():
+                o.zero_grad(set_to_none=True)
+            self.opt_cpc.zero_grad(set_to_none=True)
+            total.backward(retain_graph=True)
+            # GradNorm (:682-690): per-loss gradient norms over the 12 shared tensors
+            sh_t = list(self.m["fe_t"].return_last_layer().parameters())
+            sh_s = list(self.m["fe_s"].return_last_layer().parameters())
+            with ops.partial_backward():
+                g_t = [torch.autograd.grad(lt[i], sh_t, retain_graph=True) for i in range(2)]
+                g_s = [torch.autograd.grad(ls[i], sh_s, retain_graph=(i < 2)) for i in range(3)]
+            base_t = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_t])
+            base_s = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_s])
+        report = {k: v.detach() for k, v in L.items()}
+        report.update({k: v.detach() for k, v in aux.items()})
+        # scalars that must be identical on every rank: loss values and gradient-norm bases (10 floats)
+        scal = torch.cat([lt.detach(), ls.detach(), base_t, base_s]).contiguous()
+        return {"report": report, "scal": scal}
+
+    def _reduce(self, mid) -> None:
+        """The step's collectives: average the flat gradient bucket and the 10 GradNorm scalars over ranks."""
+        if self.bucket is None:
+            return
+        self.bucket.all_reduce(self.parameters())
+        mid["scal"].copy_(self.bucket.mean_scalars(mid["scal"]))
+
+    def _step_part_b(self, mid):
+        scal = mid["scal"]
+        lt_v, ls_v, base_t, base_s = scal[0:2], scal[2:5], scal[5:7], scal[7:10]
         if self.init_t is None:                                               # :658-664
             self.init_t, self.init_s = torch.sigmoid(lt_v).clone(), torch.sigmoid(ls_v).clone()
-        a, b, c, d = loss_coefficients(epoch)
-        # Q3: first backward + second backward (weights zeroed) == Σ wᵢ∇Lᵢ + 2·(a∇cdan + b∇fd + c∇sl_t + d∇sl_s)
-        total = torch.sum(self.w_t.detach() * lt) + torch.sum(self.w_s.detach() * ls) \
-            + 2.0 * (a * L["cdan"] + b * L["fd_s"] + c * L["sl_t"] + d * L["sl_s"])
-        for o in self.opts.values():
-            o.zero_grad(set_to_none=True)
-        self.opt_cpc.zero_grad(set_to_none=True)
-        total.backward(retain_graph=True)
-
-        # ---- GradNorm (:682-715): per-loss gradient norms over the 12 shared tensors
-        sh_t = list(self.m["fe_t"].return_last_layer().parameters())
-        sh_s = list(self.m["fe_s"].return_last_layer().parameters())
-        with ops.partial_backward():
-            g_t = [torch.autograd.grad(lt[i], sh_t, retain_graph=True) for i in range(2)]
-            g_s = [torch.autograd.grad(ls[i], sh_s, retain_graph=(i < 2)) for i in range(3)]
-        base_t = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_t])
-        base_s = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_s])
-        if self.bucket is not None:
-            base_t, base_s = self.bucket.mean_scalars(base_t), self.bucket.mean_scalars(base_s)
-        # ‖wᵢ·g‖ = |wᵢ|·‖g‖, so the norms are differentiable functions of w alone
+        # ‖wᵢ·g‖ = |wᵢ|·‖g‖, so the norms are differentiable functions of w alone (:685-715)
         nt, ns = torch.abs(self.w_t) * base_t, torch.abs(self.w_s) * base_s
         ratio_t, ratio_s = torch.sigmoid(lt_v) / self.init_t, torch.sigmoid(ls_v) / self.init_s
         inv_t, inv_s = ratio_t / ratio_t.mean(), ratio_s / ratio_s.mean()
@@ -265,9 +279,6 @@ class JointTrainer:
         const_s = (ns.detach().mean() * inv_s ** self.alpha).detach()
         g_w_t = torch.autograd.grad(torch.sum(torch.abs(nt - const_t)), self.w_t)[0]
         g_w_s = torch.autograd.grad(torch.sum(torch.abs(ns - const_s)), self.w_s)[0]
-
-        if self.bucket is not None:
-            self.bucket.all_reduce(self.parameters())
         for w, g in ((self.w_t, g_w_t), (self.w_s, g_w_s)):                   # static .grad buffers (graph-safe)
             if w.grad is None:
                 w.grad = torch.zeros_like(w)
@@ -287,20 +298,19 @@ class JointTrainer:
                 p.clamp_(-0.0005, 0.0005)
             for p in self.m["fd_s"].parameters():
                 p.clamp_(-0.01, 0.01)
-        report = {k: v.detach() for k, v in L.items()}
-        report.update({k: v.detach() for k, v in aux.items()})
+        report = dict(mid["report"])
         report.update({"w_t": self.w_t.detach().clone(), "w_s": self.w_s.detach().clone(),
                        "norms_t": nt.detach(), "norms_s": ns.detach()})
         return report
 
     # ------------------------------------------------------------------ hipGraph: capture once, replay per step
     def capture(self, x_t, y_t, x_s, y_s, epoch: int = 0, warmup: int = 11):
-        """Capture one whole step (≈10 k launches: forward, GradNorm partial backwards, backward, optimisers)
-        into a hipGraph.  Per-step inputs live in static device buffers that ``replay`` refreshes: the batch,
-        the two CPC start indices and NoiseTransfer's two accumulation ratios.  The GRL coefficients are
-        Python floats baked in at capture, so the warm-up runs until their call counters saturate
-        (20 calls, i.e. 10 steps — quirk Q7); the epoch-dependent loss coefficients are baked too, so
-        re-capture when ``loss_coefficients(epoch)`` changes."""
+        """Capture one whole step (≈12 k launches: forward, GradNorm partial backwards, backward, optimisers) into
+        hipGraphs.  Per-step inputs live in static device buffers that ``replay`` refreshes: the batch, the two CPC
+        start indices and NoiseTransfer's two accumulation ratios.  The GRL coefficients are Python floats baked in
+        at capture, so the warm-up runs until their call counters saturate (20 calls = 10 steps — quirk Q7); the
+        epoch-dependent loss coefficients are baked too: re-capture when ``loss_coefficients(epoch)`` changes.
+        Single GPU: one graph.  Data parallel: two graphs (A, B) with the eager RCCL all-reduce between them."""
         dev = self.device
         self._g_in = {"x_t": x_t.clone(), "y_t": y_t.clone(), "x_s": x_s.clone(), "y_s": y_s.clone(),
                       "t": torch.zeros(2, dtype=torch.int32, device=dev), "r": torch.ones(2, device=dev)}
@@ -316,11 +326,26 @@ class JointTrainer:
         torch.cuda.synchronize()
         if self.m["ad_net"].iter_num < self.m["ad_net"].max_iter or self.m["fd_s"].iter_num < self.m["fd_s"].max_iter:
             raise RuntimeError("capture(): GRL call counters not saturated yet; increase warmup")
-        self._graph = torch.cuda.CUDAGraph()
         self._replay_inputs(x_t, y_t, x_s, y_s, (0, 0))
-        with torch.cuda.graph(self._graph):
-            self._g_out = self._graph_body()
+        if self.bucket is None:
+            self._graphs = [torch.cuda.CUDAGraph()]
+            with torch.cuda.graph(self._graphs[0]):
+                self._g_out = self._graph_body()
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._g_mid = self._graph_part_a()
+            pool = ga.pool()
+            self._reduce(self._g_mid)                                         # eager; also fixes the bucket's buffer
+            with torch.cuda.graph(gb, pool=pool):
+                self._g_out = self._step_part_b(self._g_mid)
+            self._graphs = [ga, gb]
         return self
+
+    def _graph_part_a(self):
+        gi = self._g_in
+        return self._step_part_a(gi["x_t"], gi["y_t"], gi["x_s"], gi["y_s"], self._g_epoch, (gi["t"][0], gi["t"][1]),
+                                 (gi["r"][0], gi["r"][1]))
 
     def _graph_body(self):
         gi = self._g_in
@@ -339,7 +364,10 @@ class JointTrainer:
         gi["r"].copy_(dev[2:])
 
     def replay(self, x_t, y_t, x_s, y_s, t_samples):
-        """One step through the captured graph; returns the (static) report tensors."""
+        """One step through the captured graph(s); returns the (static) report tensors."""
         self._replay_inputs(x_t, y_t, x_s, y_s, t_samples)
-        self._graph.replay()
+        self._graphs[0].replay()
+        if len(self._graphs) == 2:
+            self._reduce(self._g_mid)
+            self._graphs[1].replay()
         return self._g_out
