@@ -15,7 +15,7 @@ import torch
 ABI_VERSION = 1
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, _LIB_NAME)
+LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
 
 
 class FstLibraryError(RuntimeError):
