@@ -269,7 +269,7 @@ extern "C" int fst_debug_stamps(unsigned long long* out_host, int reset) {
 // ------------------------------------------------------------------------------------------------
 #define PIPE_C 16
 
-template <int MB, int NB>
+template <int MB, int NB, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p, const int32_t* __restrict__ plan) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TILE_N = 128 * NB;
@@ -320,6 +320,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p
     }
     const float* xb = p.x[c[0]] + (long long)b * p.x_bs[c[0]] + (long long)c[1] * L;
     const int tbase = t0 - pv.pad_left + e[0] * pv.dil;
+    if (VEC) {
+      // 16-byte loads: the host guarantees every tap shift, L, the strides and the base pointers are multiples
+      // of 4 floats, so a float4 is entirely inside or entirely outside [0, L).  Element ev = tid + 256*i of the
+      // [PIPE_C][TILE_N/4] float4 tile: row = (tid >> (LOG_N-2)) + (1024 >> LOG_N)*i (wave-uniform), column 4*(tid & (TILE_N/4-1)).
+      const int row0 = wave_s >> (LOG_N - 8 >= 0 ? LOG_N - 8 : 0);
+      const int row_lane = LOG_N - 8 >= 0 ? 0 : ((tid & 63) >> (LOG_N - 2));      // TILE_N=128: a wave spans 2 rows
+      const int col = (tid & (TILE_N / 4 - 1)) * 4;
+      const int t = tbase + col;
+      const bool t_ok = t >= 0 && t < L;
+#pragma unroll
+      for (int i = 0; i < BV / 4; ++i) {
+        const int cc_u = (LOG_N - 8 >= 0 ? row0 : wave_s * 2) + (1024 >> LOG_N) * i;   // wave-uniform part of the row
+        const int cc = cc_u + row_lane;
+        const float* rp = xb + ((long long)cc_u * L + tbase);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t_ok && cc < c_count) v = *reinterpret_cast<const float4*>(rp + row_lane * L + col);
+        b_st[4 * i + 0] = v.x; b_st[4 * i + 1] = v.y; b_st[4 * i + 2] = v.z; b_st[4 * i + 3] = v.w;
+      }
+      return;
+    }
     // element el = tid + 256*i of the [PIPE_C][TILE_N] tile: row = (tid >> LOG_N) + (256 >> LOG_N)*i is
     // wave-uniform, column j = tid & (TILE_N-1) is the only per-lane address part
     const int row0 = wave_s >> (LOG_N - 6);
@@ -337,8 +357,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p
       const int idx = tid + 256 * i;
       if (idx < A_FLOATS / 4) reinterpret_cast<float4*>(lds + buf * STAGE_FLOATS)[idx] = a_st[i];
     }
+    if (VEC) {
 #pragma unroll
-    for (int i = 0; i < BV; ++i) lds[buf * STAGE_FLOATS + A_FLOATS + tid + 256 * i] = b_st[i];
+      for (int i = 0; i < BV / 4; ++i)
+        reinterpret_cast<float4*>(lds + buf * STAGE_FLOATS + A_FLOATS)[tid + 256 * i] =
+            make_float4(b_st[4 * i], b_st[4 * i + 1], b_st[4 * i + 2], b_st[4 * i + 3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < BV; ++i) lds[buf * STAGE_FLOATS + A_FLOATS + tid + 256 * i] = b_st[i];
+    }
   };
 
   f32x16 acc[MB][NB];
@@ -442,22 +469,26 @@ static conv_gemm_fn pick_conv_gemm(int MB, int NB) {
   return nullptr;
 }
 
-static conv_gemm_fn pick_conv_gemm_pipe(int MB, int NB) {
+template <bool VEC>
+static conv_gemm_fn pick_conv_gemm_pipe_v(int MB, int NB) {
   if (NB == 1) {
     switch (MB) {
-      case 1: return conv_gemm_pipe_kernel<1, 1>;
-      case 2: return conv_gemm_pipe_kernel<2, 1>;
-      case 4: return conv_gemm_pipe_kernel<4, 1>;
-      case 8: return conv_gemm_pipe_kernel<8, 1>;
+      case 1: return conv_gemm_pipe_kernel<1, 1, VEC>;
+      case 2: return conv_gemm_pipe_kernel<2, 1, VEC>;
+      case 4: return conv_gemm_pipe_kernel<4, 1, VEC>;
+      case 8: return conv_gemm_pipe_kernel<8, 1, VEC>;
     }
   } else if (NB == 2) {
     switch (MB) {
-      case 1: return conv_gemm_pipe_kernel<1, 2>;
-      case 2: return conv_gemm_pipe_kernel<2, 2>;
-      case 4: return conv_gemm_pipe_kernel<4, 2>;
+      case 1: return conv_gemm_pipe_kernel<1, 2, VEC>;
+      case 2: return conv_gemm_pipe_kernel<2, 2, VEC>;
+      case 4: return conv_gemm_pipe_kernel<4, 2, VEC>;
     }
   }
   return nullptr;
+}
+static conv_gemm_fn pick_conv_gemm_pipe(int MB, int NB, bool vec = false) {
+  return vec ? pick_conv_gemm_pipe_v<true>(MB, NB) : pick_conv_gemm_pipe_v<false>(MB, NB);
 }
 
 int fst_check_plan(const int32_t* ph, int plan_len, int M, const char* who) {
@@ -502,7 +533,12 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   for (int q = 0; q < pv.n_chunks; ++q) needs_x1 |= pv.chunk[4 * q] == 1;
   FST_REQUIRE(!needs_x1 || x1 != nullptr, "fst_conv_gemm: plan reads input 1 but x1 is null");
   const bool pipe = plan_is_pipeable(pv) && pick_conv_gemm_pipe(pv.MB, nb_cfg) != nullptr;
-  conv_gemm_fn fn = pipe ? pick_conv_gemm_pipe(pv.MB, nb_cfg) : pick_conv_gemm(pv.MB, nb_cfg);
+  // 16-byte B-tile loads need every address of a stage row to be 16-B aligned
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool shifts4 = pv.pad_left % 4 == 0 && (pv.ntaps == 1 || pv.dil % 4 == 0);   // every tap shift ≡ 0 (mod 4)
+  const bool vec = pipe && L % 4 == 0 && shifts4 && x0_bs % 4 == 0 && al16(x0) &&
+                   (x1 == nullptr || (x1_bs % 4 == 0 && al16(x1)));
+  conv_gemm_fn fn = pipe ? pick_conv_gemm_pipe(pv.MB, nb_cfg, vec) : pick_conv_gemm(pv.MB, nb_cfg);
   FST_REQUIRE(fn != nullptr, "fst_conv_gemm: no kernel for MB=%d NB=%d", pv.MB, nb_cfg);
   const int TILE_N = 128 * nb_cfg;
 
