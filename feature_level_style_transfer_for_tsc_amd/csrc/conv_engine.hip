@@ -609,7 +609,7 @@ struct WgradParams {
 // channels (window = TW columns, up to WG_ITEMS windows per workgroup); WIDE=true: one windowed chunk of
 // ≤ 64 channels and ≤ 128 columns (omni-scale layers, all items of a workgroup share it).
 // The next (b,t) tile is fetched global→registers while the current one is multiplied.
-template <int CB, int TW, bool WIDE>
+template <int CB, int TW, bool WIDE, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const int32_t* __restrict__ plan) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(TW == 32, "staging maps one half-wave to one 32-sample row");
@@ -701,9 +701,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
   // (half·L + l31, or lane) is the only address VGPR, so nothing large is hoisted out of the tile loop.
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int vlane = half * L + l31;
+  // VEC (narrow windows, every address 16-B aligned — checked on the host): 16-byte loads, 8 lanes per 32-sample
+  // row.  dy: row = (tid>>3) + 32*i; windows: row = tid>>3.  12 load instructions per thread per tile instead of 48.
+  const int vrow = tid >> 3, vcol = (tid & 7) * 4;
   auto fetch = [&](int tile) {
     const int b = tile / p.tiles_per_seq;
     const int tt0 = (tile - b * p.tiles_per_seq) * TW;
+    if (VEC && !WIDE) {
+      const bool tv_ok = tt0 + vcol < L;
+#pragma unroll
+      for (int i = 0; i < DYV / 4; ++i) {
+        const int m = m0 + vrow + 32 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tv_ok && m < p.M) {
+          const float* rp = (m < p.msplit) ? p.dy + ((long long)b * p.dy_bs + (long long)m * L)
+                                           : p.dy2 + ((long long)b * p.dy2_bs + (long long)(m - p.msplit) * L);
+          v = *reinterpret_cast<const float4*>(rp + tt0 + vcol);
+        }
+        dy_st[4 * i] = v.x; dy_st[4 * i + 1] = v.y; dy_st[4 * i + 2] = v.z; dy_st[4 * i + 3] = v.w;
+      }
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        if (reg_src[r] == nullptr) continue;
+        const int t = tt0 + reg_shift[r] + vcol;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < L && vrow < reg_cnt[r])
+          v = *reinterpret_cast<const float4*>(reg_src[r] + ((long long)b * reg_bs[r] + (long long)vrow * L + t));
+        x_st[r][0] = v.x; x_st[r][1] = v.y; x_st[r][2] = v.z; x_st[r][3] = v.w;
+      }
+      return;
+    }
     const bool t_ok = tt0 + l31 < L;
     // dy tile: one half-wave per 32-sample row; rows m_even + half (msplit is even: a wave's two rows share a side)
 #pragma unroll
@@ -744,6 +771,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
     }
   };
   auto commit = [&]() {
+    if (VEC && !WIDE) {
+#pragma unroll
+      for (int i = 0; i < DYV / 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dyt[(vrow + 32 * i) * DYS + vcol + k] = dy_st[4 * i + k];
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        if (reg_src[r] == nullptr || vrow >= pv.chunk_cap) continue;
+        float* reg = xreg + r * p.region_floats;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) reg[vrow * ldw + vcol + k] = x_st[r][k];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < DYV; ++i) dyt[(wave * 2 + half + 8 * i) * DYS + l31] = dy_st[i];
 #pragma unroll
@@ -880,9 +921,14 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   const size_t lds_floats = (size_t)p.n_regions * p.region_floats + (TW + 2 + 3) / 4 * 4 + (size_t)pv.MB * 32 * (TW + 1);
   const size_t lds_bytes = lds_floats * sizeof(float);
   FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_conv_wgrad: LDS %zu B exceeds 160 KiB", lds_bytes);
+  // 16-byte loads for narrow windows when every tile row address is 16-B aligned
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool shifts4 = pv.pad_left % 4 == 0 && (pv.ntaps == 1 || pv.dil % 4 == 0);
+  const bool vec = !wide && L % 4 == 0 && shifts4 && x0_bs % 4 == 0 && x1_bs % 4 == 0 && dy_bs % 4 == 0 &&
+                   dy2_bs % 4 == 0 && al16(x0) && al16(x1) && al16(dy) && al16(dy2);
   void (*fn)(WgradParams, const int32_t*);
-  if (pv.MB == 8) fn = wide ? conv_wgrad_kernel<2, TW, true> : conv_wgrad_kernel<2, TW, false>;
-  else fn = wide ? conv_wgrad_kernel<1, TW, true> : conv_wgrad_kernel<1, TW, false>;
+  if (pv.MB == 8) fn = wide ? conv_wgrad_kernel<2, TW, true, false> : (vec ? conv_wgrad_kernel<2, TW, false, true> : conv_wgrad_kernel<2, TW, false, false>);
+  else fn = wide ? conv_wgrad_kernel<1, TW, true, false> : (vec ? conv_wgrad_kernel<1, TW, false, true> : conv_wgrad_kernel<1, TW, false, false>);
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)fn, "fst_conv_wgrad")) return rc;
   dim3 grid((unsigned)p.ksplit, (unsigned)(pv.n_items / WG_ITEMS), 1);

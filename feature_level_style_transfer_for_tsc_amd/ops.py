@@ -52,6 +52,16 @@ class KernelTimer:
 KERNEL_TIMER: Optional[KernelTimer] = None
 
 
+def _vec16(plan: Plan, L: int, *tensors) -> bool:
+    """Mirror of the host-side test in csrc/conv_engine.hip for the 16-byte-load kernel variants (timer keys only)."""
+    shifts4 = plan.pad_left % 4 == 0 and (plan.ntaps == 1 or plan.dil % 4 == 0)
+    ok = L % 4 == 0 and shifts4
+    for t in tensors:
+        if t is not None:
+            ok = ok and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+    return ok
+
+
 def _plan_macs_per_step(plan: Plan, M: int) -> int:
     """Algorithmic MACs per (batch, timestep) of a plan: valid rows × live taps × real channels."""
     total = 0
@@ -176,8 +186,10 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
                             plan.length, ptr(bias), ptr(y), y_bs, ptr(res), res_bs, ptr(y2), y2_bs, msplit, m2_start, B, L,
                             M, nb, ksplit, flags, stream_ptr()), "fst_conv_gemm")
     if t0 is not None:
-        name = "conv_gemm_pipe_kernel" if (plan.pipeable and nb <= 2) else "conv_gemm_kernel"
-        key = f"{name}<{plan.MB}, {nb}>"
+        if plan.pipeable and nb <= 2:
+            key = f"conv_gemm_pipe_kernel<{plan.MB}, {nb}, {'true' if _vec16(plan, L, x0, x1) else 'false'}>"
+        else:
+            key = f"conv_gemm_kernel<{plan.MB}, {nb}>"
         if KERNEL_TIMER.detail:
             key += f" M={M} rec={plan.total_records} dil={plan.dil}"
         KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
@@ -197,7 +209,8 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
           "fst_conv_wgrad")
     if t0 is not None:
         wide = bool(((plan.entries()[:, :, 1] - plan.entries()[:, :, 0]) > 1).any())
-        key = f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}>"
+        vec = (not wide) and _vec16(plan, L, x0, x1, dy, dy2)
+        key = f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}, {'true' if vec else 'false'}>"
         if KERNEL_TIMER.detail:
             key += f" M={M} rec={plan.total_records} ksplit={ksplit}"
         KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
