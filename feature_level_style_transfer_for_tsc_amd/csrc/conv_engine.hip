@@ -16,7 +16,6 @@
 //             two 128-B segments (the full-rate shape, MI355X_MICROARCH "Global float atomics").
 #include "fst_common.h"
 #include <type_traits>
-#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient
@@ -36,6 +35,8 @@ struct ConvGemmParams {
   int msplit, m2_start;
   int B, L, M;
   int tiles_per_seq, ksplit, flags, mg_per_wg, ldw;
+  int epi_vec;       // 1: 16-byte epilogue through a wave-private LDS transpose (all outputs 16-B aligned)
+  int epi_lds_off;   // float offset of the 4 x [32][36] transpose tiles in dynamic LDS
 };
 
 // Epilogue shared by both forward kernels.  C/D layout of the 32x32 MFMA: col = lane&31 (time),
@@ -109,27 +110,88 @@ __device__ __forceinline__ void conv_epilogue_block(const ConvGemmParams& p, f32
   }
 }
 
+// 16-byte epilogue of one 32-row block: the accumulator tile (lane = time, registers = rows) is transposed through a
+// wave-private LDS tile [32][36] so that each lane owns 4 consecutive time samples of a row: 4 float4 stores (and
+// float4 loads of the residual / accumulate operands) per 32x32 tile instead of 16 dword ones, each wave-instruction
+// covering 8 rows x 128 contiguous bytes.  Loads of a tile are all issued before its stores.
+template <int MB, int NB, int MODE>
+__device__ __forceinline__ void conv_epilogue_block_vec(const ConvGemmParams& p, f32x16 (&accb)[NB], int mb, int g, int b,
+                                                        int t0, int wave_n0, int half, int l31, bool add_bias,
+                                                        float* tile) {
+  const int L = p.L, lane = half * 32 + l31;
+  const bool has_res = p.res != nullptr, acc1 = (p.flags & FST_EPI_ACC1) != 0, acc2 = (p.flags & FST_EPI_ACC2) != 0;
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = accb[nb][r];
+    const int t = t0 + wave_n0 + nb * 32 + c4;
+    const bool t_ok = t < L;
+    float4 v[4], ea[4], eb[4];
+    float* dst[4];
+    bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = (g * MB + mb) * 32 + rrow + 8 * j;
+      const bool first = m < p.msplit, second = m >= p.m2_start && m < p.M;
+      live[j] = t_ok && (first || second);
+      dst[j] = first ? p.y + ((long long)b * p.y_bs + (long long)m * L + t)
+                     : p.y2 + ((long long)b * p.y2_bs + (long long)(m - p.m2_start) * L + t);
+      ea[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      eb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == 1 && live[j]) {
+        if (first && has_res) ea[j] = *reinterpret_cast<const float4*>(p.res + ((long long)b * p.res_bs + (long long)m * L + t));
+        if ((first && acc1) || (second && acc2)) eb[j] = *reinterpret_cast<const float4*>(dst[j]);
+      }
+      const float bias_v = (add_bias && (first || second)) ? p.bias[m] : 0.f;
+      v[j] = *reinterpret_cast<const float4*>(tile + (rrow + 8 * j) * 36 + c4);
+      v[j].x += bias_v; v[j].y += bias_v; v[j].z += bias_v; v[j].w += bias_v;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!live[j]) continue;
+      float4 o = v[j];
+      if (MODE == 1) {
+        o.x += ea[j].x + eb[j].x; o.y += ea[j].y + eb[j].y; o.z += ea[j].z + eb[j].z; o.w += ea[j].w + eb[j].w;
+      }
+      if (p.flags & FST_EPI_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *reinterpret_cast<float4*>(dst[j]) = o;
+    }
+  }
+}
+
 // Blocks are expanded by hand so every accumulator index is a compile-time constant (a runtime index would send
 // the accumulators to scratch).
-template <int MB, int NB, int MODE>
+template <int MB, int NB, int MODE, bool VECE>
 __device__ __forceinline__ void conv_epilogue_mode(const ConvGemmParams& p, f32x16 (&acc)[MB][NB], int g, int b, int t0,
-                                                   int wave_n0, int half, int l31, bool add_bias) {
-#define FST_EPI_BLOCK(I) \
-  if constexpr (MB > I) conv_epilogue_block<MB, NB, MODE>(p, acc[I], I, g, b, t0, wave_n0, half, l31, add_bias);
+                                                   int wave_n0, int half, int l31, bool add_bias, float* tile) {
+#define FST_EPI_BLOCK(I)                                                                                         \
+  if constexpr (MB > I) {                                                                                        \
+    if constexpr (VECE) conv_epilogue_block_vec<MB, NB, MODE>(p, acc[I], I, g, b, t0, wave_n0, half, l31, add_bias, tile); \
+    else conv_epilogue_block<MB, NB, MODE>(p, acc[I], I, g, b, t0, wave_n0, half, l31, add_bias);               \
+  }
   FST_EPI_BLOCK(0) FST_EPI_BLOCK(1) FST_EPI_BLOCK(2) FST_EPI_BLOCK(3)
   FST_EPI_BLOCK(4) FST_EPI_BLOCK(5) FST_EPI_BLOCK(6) FST_EPI_BLOCK(7)
 #undef FST_EPI_BLOCK
 }
 
+// ``lds`` = base of the kernel's dynamic LDS (the transpose tiles live at p.epi_lds_off; the caller guarantees no
+// wave still reads anything stored there).
 template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&acc)[MB][NB], int g, int b, int t0,
-                                              int wave_n0, int half, int l31, bool add_bias) {
+                                              int wave_n0, int half, int l31, bool add_bias, float* lds) {
+  float* tile = lds + p.epi_lds_off + (wave_n0 / (NB * 32)) * (32 * 36);
+  const bool add = p.res != nullptr || (p.flags & (FST_EPI_ACC1 | FST_EPI_ACC2));
   if (p.flags & FST_EPI_ATOMIC)
-    conv_epilogue_mode<MB, NB, 2>(p, acc, g, b, t0, wave_n0, half, l31, add_bias);
-  else if (p.res != nullptr || (p.flags & (FST_EPI_ACC1 | FST_EPI_ACC2)))
-    conv_epilogue_mode<MB, NB, 1>(p, acc, g, b, t0, wave_n0, half, l31, add_bias);
+    conv_epilogue_mode<MB, NB, 2, false>(p, acc, g, b, t0, wave_n0, half, l31, add_bias, tile);
+  else if (p.epi_vec && add)
+    conv_epilogue_mode<MB, NB, 1, true>(p, acc, g, b, t0, wave_n0, half, l31, add_bias, tile);
+  else if (p.epi_vec)
+    conv_epilogue_mode<MB, NB, 0, true>(p, acc, g, b, t0, wave_n0, half, l31, add_bias, tile);
+  else if (add)
+    conv_epilogue_mode<MB, NB, 1, false>(p, acc, g, b, t0, wave_n0, half, l31, add_bias, tile);
   else
-    conv_epilogue_mode<MB, NB, 0>(p, acc, g, b, t0, wave_n0, half, l31, add_bias);
+    conv_epilogue_mode<MB, NB, 0, false>(p, acc, g, b, t0, wave_n0, half, l31, add_bias, tile);
 }
 
 template <int MB, int NB>
@@ -225,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p, const 
       }
     }
 
-    conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0);
+    conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0, lds);
   }
 }
 
@@ -301,12 +363,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p
   float b_st[BV];
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int jcol = tid & (TILE_N - 1);
-  // experiment (FST_TUNE bit 0): the wave in the odd hardware wave slot of each SIMD gets priority, so the two
-  // workgroups sharing a CU are not symmetric
-  if ((p.flags >> 16) & 1) {
-    const int wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // HW_REG_HW_ID[3:0] = WAVE_ID
-    if (wave_slot & 1) __builtin_amdgcn_s_setprio(2);
-  }
   auto fetch = [&](int q) {
     const int32_t* c = pv.chunk + 4 * q;
     const int32_t* e = ent + 4 * q;
@@ -426,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p
   }
   FST_T(tg);
 
-  conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0);
+  conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0, lds);
   FST_T(th);
   FST_ACC(6, tg, th);                                     // epilogue
   FST_ACC(7, ts0, th);                                    // whole wave
@@ -549,8 +605,7 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   p.m2_start = m2_start;
   p.B = B; p.L = L; p.M = M;
   p.tiles_per_seq = (L + TILE_N - 1) / TILE_N;
-  static const int tune = getenv("FST_TUNE") ? atoi(getenv("FST_TUNE")) : 0;
-  p.ksplit = ksplit; p.flags = flags | ((tune & 1) << 16);
+  p.ksplit = ksplit; p.flags = flags;
   // one staged window feeds every M-group when the whole K range is a single chunk (omni-scale layers)
   p.mg_per_wg = (pv.n_chunks == 1) ? pv.n_mgroups : 1;
   int max_w = 0;
@@ -572,10 +627,18 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   FST_REQUIRE(max_w > 0, "fst_conv_gemm: plan has no live taps");
   p.ldw = max_w;
   size_t lds_bytes = (size_t)pv.chunk_cap * p.ldw * sizeof(float);
+  auto al16o = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  p.epi_vec = !(flags & FST_EPI_ATOMIC) && L % 4 == 0 && y_bs % 4 == 0 && y2_bs % 4 == 0 && res_bs % 4 == 0 &&
+              al16o(y) && al16o(y2) && al16o(res);
+  const size_t epi_bytes = 4 * 32 * 36 * sizeof(float);     // one transpose tile per wave
   if (pipe) {
     p.mg_per_wg = 1;
     lds_bytes = 2 * ((size_t)(PIPE_C / 2) * pv.MB * 64 + (size_t)PIPE_C * TILE_N) * sizeof(float);
-    if (tune & 2) lds_bytes = 100 * 1024;                 // experiment: one workgroup per CU
+    p.epi_lds_off = 0;                                       // the staging buffers are dead after the last barrier
+    if (lds_bytes < epi_bytes) lds_bytes = epi_bytes;
+  } else {
+    p.epi_lds_off = (int)((lds_bytes / sizeof(float) + 3) / 4 * 4);   // after the staged window (reused across M-groups)
+    if (p.epi_vec) lds_bytes = (size_t)p.epi_lds_off * sizeof(float) + epi_bytes;
   }
   FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_conv_gemm: LDS window %zu B exceeds 160 KiB (chunk_cap=%d ldw=%d)",
               lds_bytes, pv.chunk_cap, p.ldw);
