@@ -137,6 +137,7 @@ class JointTrainer:
         self.init_t = self.init_s = None
         self.alpha = 3
         self.on_grads_ready = None                                            # test hook: called before the optimisers step
+        self._side = torch.cuda.Stream(device=device)                         # launch-bound side chains (CPC)
         for mod in self.m.values():
             mod.train()
         # GradNorm differentiates the shared OS_blocks only: their convs keep weight gradients in partial passes
@@ -196,9 +197,15 @@ class JointTrainer:
     def forward_losses(self, x_t, y_t, x_s, y_s, t_samples=(None, None), noise_ratios=None):
         m = self.m
         feat_t = m["fe_t"](x_t)
-        sl_t = m["cpc"](feat_t, t_samples[0])
         feat_s = m["dimunif"](m["fe_s"](x_s))
-        sl_s = m["cpc"](feat_s, t_samples[1])
+        # The two CPC losses are ~3 k tiny launches (MIOpen's GRU runs step by step) that would leave the chip idle in
+        # the captured graph's single chain.  Fork them onto a side stream: they (and their backward, which autograd
+        # runs on the stream of the forward op) overlap the WaveGlow passes; joined before the losses are summed.
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            sl_t = m["cpc"](feat_t, t_samples[0])
+            sl_s = m["cpc"](feat_s, t_samples[1])
         out_t, out_s = m["nf"](feat_t), m["nf"](feat_s)
         nf_t, nf_s = self.nf_loss(out_t), self.nf_loss(out_s)
         z_s2t = m["noise"](out_t[0], out_s[0], noise_ratios)
@@ -213,6 +220,9 @@ class JointTrainer:
         tr_t, tr_s2t = m["probtransfer"](pool_t), m["probtransfer"](pool_s2t)
         ce_s2t2s = F.cross_entropy(m["clf_s"].hidden(tr_s2t), y_s)
         fd = wgan_loss(m["fd_s"](tr_t), m["fd_s"](tr_s2t), m["fd_s"](pool_s))
+        main.wait_stream(self._side)
+        for t in (feat_t, feat_s):                                             # consumed on the side stream too
+            t.record_stream(self._side)
         losses = {"nf_t": nf_t, "nf_s": nf_s, "ce_t": ce_t, "sl_t": sl_t, "ce_s": ce_s, "sl_s": sl_s, "cdan": cdan,
                   "ce_s2t2s": ce_s2t2s, "fd_s": fd}
         aux = {"logit_t": logit_t, "logit_s": logit_s, "logit_s2t": logit_s2t, "feat_t": feat_t, "feat_s2t": feat_s2t}
