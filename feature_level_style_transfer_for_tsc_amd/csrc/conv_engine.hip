@@ -770,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
   auto fetch = [&](int tile) {
     const int b = tile / p.tiles_per_seq;
     const int tt0 = (tile - b * p.tiles_per_seq) * TW;
-    if (VEC && !WIDE) {
+    if (VEC) {
       const bool tv_ok = tt0 + vcol < L;
 #pragma unroll
       for (int i = 0; i < DYV / 4; ++i) {
@@ -786,11 +786,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
 #pragma unroll
       for (int r = 0; r < NREG; ++r) {
         if (reg_src[r] == nullptr) continue;
-        const int t = tt0 + reg_shift[r] + vcol;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < L && vrow < reg_cnt[r])
-          v = *reinterpret_cast<const float4*>(reg_src[r] + ((long long)b * reg_bs[r] + (long long)vrow * L + t));
-        x_st[r][0] = v.x; x_st[r][1] = v.y; x_st[r][2] = v.z; x_st[r][3] = v.w;
+        if (WIDE) {
+          // window [<=64 rows][<=128 columns] = 32 float4 per row: row = (tid>>5) + 8*i, column 4*(tid&31)
+          const int wc = (tid & 31) * 4;
+          const int t = tt0 + reg_shift[r] + wc;
+          const bool ok = wc < reg_width[r] && t >= 0 && t < L;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int cc = (tid >> 5) + 8 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && cc < reg_cnt[r])
+              v = *reinterpret_cast<const float4*>(reg_src[r] + ((long long)b * reg_bs[r] + (long long)cc * L + t));
+            x_st[r][4 * i] = v.x; x_st[r][4 * i + 1] = v.y; x_st[r][4 * i + 2] = v.z; x_st[r][4 * i + 3] = v.w;
+          }
+        } else {
+          const int t = tt0 + reg_shift[r] + vcol;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (t >= 0 && t < L && vrow < reg_cnt[r])
+            v = *reinterpret_cast<const float4*>(reg_src[r] + ((long long)b * reg_bs[r] + (long long)vrow * L + t));
+          x_st[r][0] = v.x; x_st[r][1] = v.y; x_st[r][2] = v.z; x_st[r][3] = v.w;
+        }
       }
       return;
     }
@@ -834,17 +849,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
     }
   };
   auto commit = [&]() {
-    if (VEC && !WIDE) {
+    if (VEC) {
 #pragma unroll
       for (int i = 0; i < DYV / 4; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) dyt[(vrow + 32 * i) * DYS + vcol + k] = dy_st[4 * i + k];
 #pragma unroll
       for (int r = 0; r < NREG; ++r) {
-        if (reg_src[r] == nullptr || vrow >= pv.chunk_cap) continue;
+        if (reg_src[r] == nullptr) continue;
         float* reg = xreg + r * p.region_floats;
+        if (WIDE) {
+          const int wc = (tid & 31) * 4;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) reg[vrow * ldw + vcol + k] = x_st[r][k];
+          for (int i = 0; i < 8; ++i) {
+            const int cc = (tid >> 5) + 8 * i;
+            if (cc < pv.chunk_cap && wc < reg_width[r]) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) reg[cc * ldw + wc + k] = x_st[r][4 * i + k];
+            }
+          }
+        } else if (vrow < pv.chunk_cap) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) reg[vrow * ldw + vcol + k] = x_st[r][k];
+        }
       }
       return;
     }
@@ -987,11 +1014,24 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   // 16-byte loads for narrow windows when every tile row address is 16-B aligned
   auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool shifts4 = pv.pad_left % 4 == 0 && (pv.ntaps == 1 || pv.dil % 4 == 0);
-  const bool vec = !wide && L % 4 == 0 && shifts4 && x0_bs % 4 == 0 && x1_bs % 4 == 0 && dy_bs % 4 == 0 &&
+  // windowed plans: the window of every (M-group, chunk) must also START on a multiple of 4 samples and be a
+  // multiple of 4 wide
+  bool starts4 = true;
+  for (int q = 0; q < pv.n_chunks; ++q)
+    for (int g = 0; g < pv.n_mgroups; ++g) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      if (e[1] > e[0] && ((e[0] * pv.dil - pv.pad_left) % 4 != 0 || ((e[1] - 1 - e[0]) * pv.dil) % 4 != 0)) starts4 = false;
+    }
+  const bool vec = L % 4 == 0 && (wide ? starts4 : shifts4) && x0_bs % 4 == 0 && x1_bs % 4 == 0 && dy_bs % 4 == 0 &&
                    dy2_bs % 4 == 0 && al16(x0) && al16(x1) && al16(dy) && al16(dy2);
   void (*fn)(WgradParams, const int32_t*);
-  if (pv.MB == 8) fn = wide ? conv_wgrad_kernel<2, TW, true, false> : (vec ? conv_wgrad_kernel<2, TW, false, true> : conv_wgrad_kernel<2, TW, false, false>);
-  else fn = wide ? conv_wgrad_kernel<1, TW, true, false> : (vec ? conv_wgrad_kernel<1, TW, false, true> : conv_wgrad_kernel<1, TW, false, false>);
+  if (pv.MB == 8) {
+    fn = wide ? (vec ? conv_wgrad_kernel<2, TW, true, true> : conv_wgrad_kernel<2, TW, true, false>)
+              : (vec ? conv_wgrad_kernel<2, TW, false, true> : conv_wgrad_kernel<2, TW, false, false>);
+  } else {
+    fn = wide ? (vec ? conv_wgrad_kernel<1, TW, true, true> : conv_wgrad_kernel<1, TW, true, false>)
+              : (vec ? conv_wgrad_kernel<1, TW, false, true> : conv_wgrad_kernel<1, TW, false, false>);
+  }
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)fn, "fst_conv_wgrad")) return rc;
   dim3 grid((unsigned)p.ksplit, (unsigned)(pv.n_items / WG_ITEMS), 1);

@@ -209,7 +209,15 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
           "fst_conv_wgrad")
     if t0 is not None:
         wide = bool(((plan.entries()[:, :, 1] - plan.entries()[:, :, 0]) > 1).any())
-        vec = (not wide) and _vec16(plan, L, x0, x1, dy, dy2)
+        if wide:
+            en = plan.entries()
+            live = en[:, :, 1] > en[:, :, 0]
+            starts4 = bool((((en[:, :, 0] * plan.dil - plan.pad_left) % 4 == 0) | ~live).all()) and \
+                bool(((((en[:, :, 1] - 1 - en[:, :, 0]) * plan.dil) % 4 == 0) | ~live).all())
+            vec = L % 4 == 0 and starts4 and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0)
+                                                  for t in (x0, x1, dy, dy2))
+        else:
+            vec = _vec16(plan, L, x0, x1, dy, dy2)
         key = f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}, {'true' if vec else 'false'}>"
         if KERNEL_TIMER.detail:
             key += f" M={M} rec={plan.total_records} ksplit={ksplit}"
