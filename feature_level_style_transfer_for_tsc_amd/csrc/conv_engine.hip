@@ -35,6 +35,7 @@ struct ConvGemmParams {
   int msplit, m2_start;
   int B, L, M;
   int tiles_per_seq, ksplit, flags, mg_per_wg, ldw;
+  int stage_vec;     // 1: inputs are 16-B aligned (L, strides, bases): windows may be staged with float4 loads
   int epi_vec;       // 1: 16-byte epilogue through a wave-private LDS transpose (all outputs 16-B aligned)
   int epi_lds_off;   // float offset of the 4 x [32][36] transpose tiles in dynamic LDS
 };
@@ -227,6 +228,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p, const 
     const int c_pad = (c_count + 1) & ~1;
     const float* xb = p.x[src] + (long long)b * p.x_bs[src] + (long long)c_begin * L;
     const int tbase = t0 - pv.pad_left + jlo;
+    if (p.stage_vec && (tbase & 3) == 0 && (width & 3) == 0 && (ldw & 3) == 0) {
+      // 16-byte staging: L, strides and bases are multiples of 4 floats (host-checked), so a float4 is entirely
+      // inside or outside [0, L)
+      const int w4 = width >> 2;
+      for (int cc = wave; cc < c_pad; cc += 4) {
+        const float* row = xb + (long long)cc * L;
+        float4* dst = reinterpret_cast<float4*>(lds + cc * ldw);
+        const bool live = cc < c_count;
+        for (int j4 = lane; j4 < w4; j4 += 64) {
+          const int t = tbase + 4 * j4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (live && t >= 0 && t < L) v = *reinterpret_cast<const float4*>(row + t);
+          dst[j4] = v;
+        }
+      }
+      return;
+    }
     for (int cc = wave; cc < c_pad; cc += 4) {
       const float* row = xb + (long long)cc * L;
       float* dst = lds + cc * ldw;
@@ -266,23 +284,42 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p, const 
       }
       if (hi <= lo) continue;
       const int c_pad = (pv.chunk[4 * q + 2] + 1) & ~1;
+      const int half_c = c_pad >> 1;
+      const int nk = (hi - lo) * half_c;                     // k-steps of this (M-group, chunk): tap-major
       const float* ap = p.a + (long long)e[2] * (MB * 64) + lane;
-      for (int tap = lo; tap < hi; ++tap) {
-        const float* bp = lds + half * ldw + (tap * dil - jlo) + wave_n0 + l31;
-#pragma unroll 2
-        for (int cp = 0; cp < c_pad; cp += 2) {
-          float av[MB], bv[NB];
+      // The A records stream from L2 (≈500+ cycles) while a k-step is only MB*NB*64 cycles of MFMA: keep RING
+      // k-steps of A in flight in a register ring (statically indexed through the unrolled inner loop).
+      constexpr int RING = (MB * NB >= 8) ? 2 : (MB * NB >= 4 ? 4 : 8);
+      float ring[RING][MB];
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) av[mb] = ap[mb * 64];
+      for (int j = 0; j < RING; ++j) {
+        const int kk = j < nk ? j : nk - 1;
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[nb * 32];
-          ap += MB * 64;
-          bp += 2 * ldw;
+        for (int mb = 0; mb < MB; ++mb) ring[j][mb] = ap[((long long)kk * MB + mb) * 64];
+      }
+      int tap = lo, cp = 0;
+      const float* bbase = lds + half * ldw - jlo + wave_n0 + l31;
+      for (int kb = 0; kb < nk; kb += RING) {
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
+        for (int j = 0; j < RING; ++j) {
+          const int k = kb + j;
+          if (k < nk) {
+            float bv[NB], av[MB];
+            const float* bp = bbase + tap * dil + 2 * cp * ldw;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[nb * 32];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) av[mb] = ring[j][mb];
+            const int kn = k + RING < nk ? k + RING : nk - 1;  // refill this slot (clamped at the tail)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) ring[j][mb] = ap[((long long)kn * MB + mb) * 64];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+            if (++cp == half_c) { cp = 0; ++tap; }
+          }
         }
       }
     }
@@ -625,9 +662,10 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
     }
   }
   FST_REQUIRE(max_w > 0, "fst_conv_gemm: plan has no live taps");
-  p.ldw = max_w;
+  p.ldw = (max_w + 3) & ~3;                               // 16-B aligned LDS rows (float4 staging)
   size_t lds_bytes = (size_t)pv.chunk_cap * p.ldw * sizeof(float);
   auto al16o = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  p.stage_vec = L % 4 == 0 && x0_bs % 4 == 0 && al16o(x0) && (x1 == nullptr || (x1_bs % 4 == 0 && al16o(x1)));
   p.epi_vec = !(flags & FST_EPI_ATOMIC) && L % 4 == 0 && y_bs % 4 == 0 && y2_bs % 4 == 0 && res_bs % 4 == 0 &&
               al16o(y) && al16o(y2) && al16o(res);
   const size_t epi_bytes = 4 * 32 * 36 * sizeof(float);     // one transpose tile per wave

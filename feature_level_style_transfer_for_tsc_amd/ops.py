@@ -267,13 +267,16 @@ class ConvSpec:
 
     def nb_for(self, B: int, L: int, mb: int, windowed_c: int, halo: int) -> int:
         """N-blocks (32 timesteps each) per wave.  windowed_c > 0: the whole-window kernel (omni-scale layers with
-        many taps), whose LDS window must fit; otherwise the pipelined kernel, which has NB ∈ {1, 2}."""
+        many taps; channels are chunked to fit the LDS budget by ``_chunking``); otherwise the pipelined kernel,
+        which has NB ∈ {1, 2}."""
         tiles128 = (L + 127) // 128
         best = 1
         for nb in ((4, 2, 1) if windowed_c else (2, 1)):
             if mb * nb > 8 or nb > max(1, tiles128):
                 continue
-            if windowed_c and ((windowed_c + 1) & ~1) * (128 * nb + halo) * 4 > LDS_BUDGET:
+            if windowed_c and windowed_c <= 64 and ((windowed_c + 1) & ~1) * (128 * nb + halo) * 4 > LDS_BUDGET:
+                continue
+            if windowed_c > 64 and nb > 2:
                 continue
             best = nb
             if B * ((L + 128 * nb - 1) // (128 * nb)) >= 512:
@@ -289,7 +292,7 @@ class ConvSpec:
     def _windowed(self, channels: int) -> bool:
         """Many dense taps over few channels (omni-scale layers): stage one [C][T+halo] window and slide the taps
         over it.  Everything else is cut into single-tap 16-channel stages for the pipelined kernel."""
-        return self.dil == 1 and self.ntaps > 3 and channels <= 64
+        return self.dil == 1 and self.ntaps > 3
 
     def _chunking(self, channels: int, nb: int, ntaps: int) -> Tuple[int, bool]:
         """(chunk_c, split_taps)"""
