@@ -299,27 +299,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p, const 
       }
       int tap = lo, cp = 0;
       const float* bbase = lds + half * ldw - jlo + wave_n0 + l31;
-      for (int kb = 0; kb < nk; kb += RING) {
+      auto kstep = [&](const float (&av)[MB]) {
+        float bv[NB];
+        const float* bp = bbase + tap * dil + 2 * cp * ldw;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[nb * 32];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
+        if (++cp == half_c) { cp = 0; ++tap; }
+      };
+      int kb = 0;
+      for (; kb + RING <= nk; kb += RING) {                   // full blocks: no branches around the ring loads
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
-          const int k = kb + j;
-          if (k < nk) {
-            float bv[NB], av[MB];
-            const float* bp = bbase + tap * dil + 2 * cp * ldw;
+          float av[MB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) bv[nb] = bp[nb * 32];
+          for (int mb = 0; mb < MB; ++mb) av[mb] = ring[j][mb];
+          const int kn = kb + j + RING < nk ? kb + j + RING : nk - 1;   // refill this slot (clamped at the tail)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) av[mb] = ring[j][mb];
-            const int kn = k + RING < nk ? k + RING : nk - 1;  // refill this slot (clamped at the tail)
+          for (int mb = 0; mb < MB; ++mb) ring[j][mb] = ap[((long long)kn * MB + mb) * 64];
+          kstep(av);
+        }
+      }
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) ring[j][mb] = ap[((long long)kn * MB + mb) * 64];
+      for (int j = 0; j < RING; ++j) {                        // tail: operands are already in the ring
+        if (kb + j < nk) {
+          float av[MB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-              for (int nb = 0; nb < NB; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb], bv[nb], acc[mb][nb], 0, 0, 0);
-            if (++cp == half_c) { cp = 0; ++tap; }
-          }
+          for (int mb = 0; mb < MB; ++mb) av[mb] = ring[j][mb];
+          kstep(av);
         }
       }
     }

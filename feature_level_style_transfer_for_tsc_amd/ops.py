@@ -16,6 +16,7 @@ from .plan import Plan, Segment, build_plan, pick_mb
 
 EPI_RELU, EPI_ACC2, EPI_ATOMIC, EPI_ACC1 = 1, 2, 4, 8
 LDS_BUDGET = 96 * 1024
+LDS_MULTI_CHUNK = 44 * 1024
 PIPE_C = 16            # channels per stage of the pipelined conv kernel (csrc/conv_engine.hip)
 
 _PARTIAL_BACKWARD = False
@@ -302,6 +303,7 @@ class ConvSpec:
         cap = (LDS_BUDGET // (4 * (128 * nb + halo))) & ~1
         if channels <= cap:
             return (channels + 1) & ~1, False
+        cap = (LDS_MULTI_CHUNK // (4 * (128 * nb + halo))) & ~1                    # several chunks: keep 2+ workgroups per CU
         n = (channels + cap - 1) // cap
         return ((channels + n - 1) // n + 1) & ~1, False
 
