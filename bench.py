@@ -155,8 +155,15 @@ def main() -> None:
         dom = ks[dom_key]
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
         conv_ms = sum(v["total_ms"] for v in ks.values()) / n_timer_steps
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")             # PMC passes cannot run inside bench.py
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj["hbm_bytes_per_launch"].get(dom_key), tj["source"]
         roofline = {"bound": "mfma", "kernel": dom_key, "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                    "algorithmic_flop_per_launch": dom["flops"] / dom["launches"],
                     "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches"] / n_timer_steps,
                     "conv_engine_ms_per_step": conv_ms,
                     "kernels": {k: {"avg_us": round(v["avg_us"], 1), "launches_per_step": v["launches"] / n_timer_steps,
