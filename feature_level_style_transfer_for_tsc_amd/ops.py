@@ -338,7 +338,8 @@ class ConvSpec:
         if key not in self._plans:
             cmax = max(self.C0, self.C1)
             if self._windowed(cmax):
-                chunk_c, split = (cmax + 1) & ~1, False           # one [C][32+halo] window, all taps
+                n = (cmax + 63) // 64                             # [<=64 channels][32+halo] windows, all taps
+                chunk_c, split = ((cmax + n - 1) // n + 1) & ~1, False
             else:
                 chunk_c, split = 32, True                         # single-tap 32-channel chunks = one row-block each
             self._plans[key] = build_plan(self.M, self._fwd_segments(), self.ntaps, self.dil, self.pad_left,
