@@ -23,6 +23,29 @@ def close(got, want, tol, what, scale=None):
     assert err <= tol * s, f"{what}: max err {err:.3e}, scale {s:.3e}, tol {tol}"
 
 
+def close_piecewise(got, want, tol, what):
+    """Gradient of a ReLU network at a random point: a pre-activation within rounding distance of 0 may take the
+    other branch on the GPU than on the CPU (about 0.4 expected flips per ReLU layer at 2x50x5000 elements and 1e-6
+    relative rounding), which changes dx by O(scale) inside that element's receptive field only (<= 89+89+2 samples x 9
+    channels).  So: every element within tol except inside at most 4 receptive-field-sized windows (<= 3 % of the
+    elements), and a small relative L2 error overall."""
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    s = max(1e-6, float(want.abs().max()))
+    err = (got - want).abs()
+    bad = err > tol * s
+    frac = float(bad.double().mean())
+    l2 = float((got - want).norm() / want.norm())
+    bad_bt = bad.any(dim=1)                                          # [B, L]
+    windows = 0
+    for b in range(bad_bt.shape[0]):
+        t = torch.nonzero(bad_bt[b]).flatten()
+        if len(t):
+            windows += 1 + int((t[1:] - t[:-1] > 200).sum())
+    msg = f"{what}: max err {float(err.max()):.3e}, scale {s:.3e}, outliers {frac:.2e} in {windows} windows, rel L2 {l2:.2e}"
+    print(msg)
+    assert frac <= 3e-2 and windows <= 4 and l2 <= 2e-3, msg
+
+
 def test_config0_gunpoint_shaped_classifier_step():
     gen = torch.Generator().manual_seed(150)
     fe_spec, clf_spec = R.train_specs(150, 1)
@@ -56,11 +79,63 @@ def test_config3_nine_channel_long_sequence_feature_extractor():
     y = fe(xd)
     (y * r.to(DEV)).sum().backward()
     close(y, yo, 1e-4, "FE(9ch, L=5000) forward")
-    close(xd.grad, xo.grad, 1e-3, "FE(9ch, L=5000) dx")
+    close_piecewise(xd.grad, xo.grad, 1e-3, "FE(9ch, L=5000) dx")
+    # parameter gradients: a flipped ReLU moves one sample's contribution (cotangent x activation, O(10) against a
+    # gradient scale of O(1000)); the linear kernels themselves are held to 1e-4 at this shape by the test below
     want = {k: v.grad for k, v in P.items() if v.grad is not None}
     scale = max(float(v.abs().max()) for v in want.values())
     for k, p in fe.named_parameters():
-        close(p.grad, want[k], 1e-3, f"FE(9ch, L=5000) grad {k}", scale=scale)
+        close(p.grad, want[k], 2e-2, f"FE(9ch, L=5000) grad {k}", scale=scale)
+        l2 = float((p.grad.double().cpu() - want[k].double()).norm()) / max(1e-9, float(want[k].double().norm()))
+        assert l2 <= 5e-3 or float(want[k].abs().max()) < 1e-3 * scale, (k, l2)
+
+
+def test_config3_every_conv_of_the_long_sequence_extractor_is_exact():
+    """The linear pieces of config 3 (no ReLU in the way): forward, data gradient, live-tap and dense (Q1) weight
+    gradient of each omni-scale layer and of the 1x1 shortcut at B=2, C_in=9, L=5000 (39 full 128-sample tiles + 8)
+    against fp64 torch."""
+    import torch.nn.functional as F
+    from feature_level_style_transfer_for_tsc_amd import ops
+    from feature_level_style_transfer_for_tsc_amd.structure import out_channels, row_live_ranges
+    B, L, CIN = 2, 5000, 9
+    fe_spec, _ = R.train_specs(L, CIN)
+    g = torch.Generator().manual_seed(9)
+    f = lambda t: t.detach().float().to(DEV)
+
+    def ref_conv(x, w, pl, nt):
+        return F.conv1d(F.pad(x, (pl, nt - 1 - pl)), w)
+
+    for name, layer in (("L0", fe_spec[0]), ("L1", fe_spec[1]), ("L2", fe_spec[2]), ("shortcut", [(CIN, 50, 1)])):
+        C0, kmax, M = layer[0][0], layer[-1][2], out_channels(layer)
+        live = row_live_ranges(layer) if name != "shortcut" else None
+        w = torch.randn(M, C0, kmax, generator=g, dtype=torch.float64) / (C0 * 3) ** 0.5
+        if live:
+            for m, (lo, hi) in enumerate(live):
+                w[m, :, :lo] = 0
+                w[m, :, hi:] = 0
+        w.requires_grad_(True)
+        x = torch.randn(B, C0, L, generator=g, dtype=torch.float64, requires_grad=True)
+        pl = int((kmax - 1) / 2)
+        y = ref_conv(x, w, pl, kmax)
+        dy = torch.randn(B, M, L, generator=g, dtype=torch.float64)
+        dx_ref, dw_dense_ref = torch.autograd.grad(y, (x, w), dy)
+        dw_live_ref = dw_dense_ref.clone()
+        if live:
+            for m, (lo, hi) in enumerate(live):
+                dw_live_ref[m, :, :lo] = 0
+                dw_live_ref[m, :, hi:] = 0
+        spec = ops.ConvSpec(M, C0, kmax, 1, pl, row_live=live)
+        close(spec.forward(f(x), None, f(w), None, None), y, 2e-5, f"{name} forward")
+        close(spec.grad_x0(f(dy), f(w)), dx_ref, 2e-5, f"{name} dx")
+        dw = spec.grad_w(f(x), None, f(dy))[0]
+        if live:                                                         # live-only plans cover a per-block superset
+            for m, (lo, hi) in enumerate(live):
+                dw[m, :, :lo] = 0
+                dw[m, :, hi:] = 0
+        close(dw, dw_live_ref, 1e-4, f"{name} dW (live taps)")
+        if live:
+            dense = ops.ConvSpec(M, C0, kmax, 1, pl, row_live=live, dense_dw=True)
+            close(dense.grad_w(f(x), None, f(dy))[0], dw_dense_ref, 1e-4, f"{name} dW (dense, Q1)")
 
 
 def test_config4_joint_forward_losses_L1024():
