@@ -7,7 +7,7 @@
 
 #include "../../include/fst_hip.h"
 
-#define FST_PLAN_HDR 16   // ints; see plan.py (fields 0..9 used)
+#define FST_PLAN_HDR FST_PLAN_HEADER   // 16 ints; see plan.py (fields 0..9 used)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

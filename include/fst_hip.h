@@ -34,15 +34,20 @@ const char* fst_last_error(void);
  * dilated, optionally two-input) 1-D convolution is cut into K-chunks and 32-row M-blocks for the
  * f32 MFMA implicit GEMM.  It is built on the host (plan.py) once per layer shape.
  *
- *   plan[0..7]   header: n_chunks, n_mgroups, MB (32-row blocks per M-group), ntaps, dil, pad_left,
- *                        chunk_cap (max padded channels per chunk, even), total_records
- *   plan[8 + 4*q ...]                 chunk q:        src (0|1), c_begin, c_count, 0
- *   plan[8 + 4*n_chunks + 4*(g*n_chunks+q) ...]  (g,q): tap_lo, tap_hi, record_offset, 0
+ *   plan[0..15]  header: n_chunks, n_mgroups, MB (32-row blocks per M-group), ntaps, dil, pad_left,
+ *                        chunk_cap (max padded channels per chunk, even), total_records,
+ *                        n_items, items_per_wg, 6 reserved (0)
+ *   plan[16 + 4*q ...]                 chunk q:        src (0|1), c_begin, c_count, 0
+ *   plan[16 + 4*n_chunks + 4*(g*n_chunks+q) ...]  (g,q): tap_lo, tap_hi, record_offset, 0
+ *   plan[16 + 4*n_chunks*(1+n_mgroups) + 4*i ...] item i (weight-gradient plans only):
+ *                                                       g, q, row_block, 0      (q < 0: padding item)
  *
  * A "record" is MB*64 floats: for one (tap, channel pair) the MB A-operand registers of one
  * v_mfma_f32_32x32x2_f32 k-step (lane l ↔ row l&31 of the block, channel parity l>>5).
+ * Every entry point takes the table twice: `plan_dev` (read by the kernels through scalar loads) and
+ * `plan_host` + `plan_len` (the same ints in host memory, used to validate shapes and size the launch).
  * ------------------------------------------------------------------------------------------- */
-#define FST_PLAN_HEADER 8
+#define FST_PLAN_HEADER 16
 
 /* Weight source description for pack/unpack: element (m, c, tap) of input `s` lives at
  * w[s][off0 + m*sm + c*sc + tap*st].  Forward convs use (sm, sc, st) = (C*ntaps, ntaps, 1);
