@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
@@ -33,6 +33,7 @@ _SIGNATURES = {
     "fst_version": (c_int, []),
     "fst_last_error": (c_char_p, []),
     "fst_pack_weights": (c_int, [_I32P, _I32P, c_int, POINTER(WSrc), POINTER(WSrc), c_int, c_int, c_int, c_int, _P, c_void_p]),
+    "fst_pack_weights_bf16x3": (c_int, [_I32P, _I32P, c_int, POINTER(WSrc), POINTER(WSrc), c_int, c_int, c_int, c_int, _P, c_void_p]),
     "fst_unpack_weights": (c_int, [_I32P, _I32P, c_int, _P, c_int, _P, c_int64, c_int64, c_int64, c_int64,
                                    _P, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "fst_mask_taps": (c_int, [_P, _I32P, _I32P, c_int, c_int, c_int, c_void_p]),

@@ -537,6 +537,181 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p
   FST_FLUSH;
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient on the bf16 matrix cores with split operands ("bf16x3").
+//
+// Same plans, stage structure, pipeline and epilogue as conv_gemm_pipe_kernel; the product of a stage is formed
+// as  hi(A)·hi(B) + hi(A)·lo(B) + lo(A)·hi(B)  by three v_mfma_f32_32x32x16_bf16 (fp32 accumulate), where
+// v = hi + lo + O(2^-18 |v|), hi = bf16_rne(v), lo = bf16_rne(v − hi).  One stage (≤ 16 channels of one tap) is
+// exactly one 16-deep k-step: 3·MB·NB MFMAs of 32 cycles instead of 8·MB·NB of 64.
+//   A: the image written by fst_pack_weights_bf16x3 — per stage and 32-row block 1 KiB of hi fragments then
+//      1 KiB of lo fragments, copied to LDS verbatim and read back with one ds_read_b128 per fragment.
+//   B: the [16 channels][TILE_N] tile of shifted input rows is fetched as 16-byte loads at 16-byte aligned
+//      times (plus the following 16 bytes when the tap shift is not a multiple of 4 samples; the sub-shift is
+//      wave-uniform), split into hi / lo on the way into LDS (two [16][TILE_N] bf16 images, row stride
+//      2·TILE_N + 64 bytes) and read as MFMA B fragments (k-strided) with ds_read_b64_tr_b16: a 32-lane half
+//      reads 4 rows × 64 contiguous bytes that fall into 4 disjoint bank groups.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define FST_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// two floats -> (hi pair, lo pair), each a dword of two round-to-nearest bf16 (first element in the low half)
+__device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256, 2) void conv_gemm_bf3_kernel(ConvGemmParams p, const int32_t* __restrict__ plan) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TILE_N = 128 * NB;
+  constexpr int RS = 2 * TILE_N + 64;                  // bytes per image row
+  constexpr int A_BYTES = MB * 2048;
+  constexpr int STAGE_BYTES = A_BYTES + 2 * PIPE_C * RS;
+  constexpr int AV = (A_BYTES / 16 + 255) / 256;       // 16-byte pieces of A per thread per stage
+  constexpr int BR = PIPE_C * (TILE_N / 4) / 256;      // float4 rows of the B tile per thread per stage (NB=2: 4, NB=1: 2)
+  constexpr int LOG_N = NB == 1 ? 7 : 8;
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const PlanView pv = plan_view(plan);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.tiles_per_seq;
+  const int t0 = (blockIdx.x - b * p.tiles_per_seq) * TILE_N;
+  const int g = blockIdx.y;
+  const int q_begin = (int)(((long long)blockIdx.z * pv.n_chunks) / p.ksplit);
+  const int q_end = (int)(((long long)(blockIdx.z + 1) * pv.n_chunks) / p.ksplit);
+  const int wave_n0 = wave * NB * 32;
+  const int L = p.L;
+  const int32_t* ent = pv.mg + 4 * (g * pv.n_chunks);
+
+  auto next_live = [&](int q) {
+    while (q < q_end && ent[4 * q + 1] <= ent[4 * q]) ++q;
+    return q;
+  };
+
+  uint4 a_st[AV];
+  float4 b_lo[BR], b_hi4[BR];                          // aligned 16-byte pieces: [t, t+4) and [t+4, t+8)
+  int sub = 0;                                         // tap shift mod 4 of the stage in flight (uniform)
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // element (row, col4) of the [PIPE_C][TILE_N/4] float4 tile handled by this thread in pass i:
+  // row = row_u(i) + row_lane (row_u wave-uniform), column 4*(tid & (TILE_N/4-1))
+  const int row_lane = NB == 1 ? (lane >> 5) : 0;
+  const int col = (tid & (TILE_N / 4 - 1)) * 4;
+  auto fetch = [&](int q) {
+    const int32_t* c = pv.chunk + 4 * q;
+    const int32_t* e = ent + 4 * q;
+    const int c_count = c[2];
+    const uint4* asrc = reinterpret_cast<const uint4*>(p.a) + (long long)e[3] * (A_BYTES / 16);
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int idx = tid + 256 * i;
+      a_st[i] = (A_BYTES / 16 >= 256 * (i + 1) || idx < A_BYTES / 16) ? asrc[idx] : make_uint4(0, 0, 0, 0);
+    }
+    const float* xb = p.x[c[0]] + (long long)b * p.x_bs[c[0]] + (long long)c[1] * L;
+    const int tbase = t0 - pv.pad_left + e[0] * pv.dil;
+    sub = tbase & 3;
+    const int t = (tbase & ~3) + col;                  // 16-byte aligned (L, strides and bases are multiples of 4 floats)
+    const bool ok0 = t >= 0 && t < L, ok1 = sub != 0 && t + 4 >= 0 && t + 4 < L;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int cc_u = (NB == 1 ? wave_s * 2 : wave_s) + (1024 >> LOG_N) * i;
+      const int cc = cc_u + row_lane;
+      const float* rp = xb + ((long long)cc_u * L + (long long)row_lane * L + t);
+      const bool row_ok = cc < c_count;
+      // unconditional loads from a safe address when masked: no exec-mask branch, no per-load wait
+      const float4 v0 = *reinterpret_cast<const float4*>((ok0 && row_ok) ? rp : p.x[0]);
+      const float4 v1 = *reinterpret_cast<const float4*>((ok1 && row_ok) ? rp + 4 : p.x[0]);
+      b_lo[i] = (ok0 && row_ok) ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
+      b_hi4[i] = (ok1 && row_ok) ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit = [&](int buf) {
+    char* base = ldsb + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+      const int idx = tid + 256 * i;
+      if (A_BYTES / 16 >= 256 * (i + 1) || idx < A_BYTES / 16) reinterpret_cast<uint4*>(base)[idx] = a_st[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const float4 u = b_lo[i], w = b_hi4[i];
+      float e0, e1, e2, e3;
+      if (sub == 0) { e0 = u.x; e1 = u.y; e2 = u.z; e3 = u.w; }
+      else if (sub == 1) { e0 = u.y; e1 = u.z; e2 = u.w; e3 = w.x; }
+      else if (sub == 2) { e0 = u.z; e1 = u.w; e2 = w.x; e3 = w.y; }
+      else { e0 = u.w; e1 = w.x; e2 = w.y; e3 = w.z; }
+      unsigned h0, h1, l0, l1;
+      split_bf16_pair(e0, e1, h0, l0);
+      split_bf16_pair(e2, e3, h1, l1);
+      const int cc = (NB == 1 ? wave_s * 2 : wave_s) + (1024 >> LOG_N) * i + row_lane;
+      char* dst = base + A_BYTES + cc * RS + col * 2;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(dst + PIPE_C * RS) = make_uint2(l0, l1);
+    }
+  };
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  // per-lane byte offset of the transposed reads inside a B image: lane 4q+pp of the 16-lane group gr supplies
+  // row 8*half + q, columns wave_n0 + 16*(gr&1) + 4*pp .. +3 (ds_read_b64_tr_b16 hands lane i column i of the block)
+  const int gr = lane >> 4, u16 = lane & 15;
+  const int boff = (8 * half + (u16 >> 2)) * RS + 2 * (wave_n0 + 16 * (gr & 1) + 4 * (u16 & 3));
+
+  int q = next_live(q_begin);
+  if (q < q_end) {
+    fetch(q);
+    commit(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  while (q < q_end) {
+    const int qn = next_live(q + 1);
+    if (qn < q_end) fetch(qn);
+    const char* base = ldsb + buf * STAGE_BYTES;
+    const char* bh_img = base + A_BYTES + boff;
+    const char* bl_img = bh_img + PIPE_C * RS;
+    bf16x8 bh[NB], bl[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FST_LDS_PTR(s16x4, bh_img + nb * 64));
+      const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FST_LDS_PTR(s16x4, bh_img + nb * 64 + 4 * RS));
+      const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FST_LDS_PTR(s16x4, bl_img + nb * 64));
+      const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FST_LDS_PTR(s16x4, bl_img + nb * 64 + 4 * RS));
+      bh[nb] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+      bl[nb] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + mb * 2048 + lane * 16);
+      const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nb], acc[mb][nb], 0, 0, 0);
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nb], acc[mb][nb], 0, 0, 0);
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nb], acc[mb][nb], 0, 0, 0);
+      }
+    }
+    if (qn < q_end) commit(buf ^ 1);
+    __syncthreads();
+    q = qn;
+    buf ^= 1;
+  }
+
+  conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0, lds);
+}
+
 static bool plan_is_pipeable(const PlanView& pv) {
   for (int q = 0; q < pv.n_chunks; ++q) {
     if (((pv.chunk[4 * q + 2] + 1) & ~1) > PIPE_C) return false;
@@ -595,6 +770,24 @@ static conv_gemm_fn pick_conv_gemm_pipe(int MB, int NB, bool vec = false) {
   return vec ? pick_conv_gemm_pipe_v<true>(MB, NB) : pick_conv_gemm_pipe_v<false>(MB, NB);
 }
 
+static conv_gemm_fn pick_conv_gemm_bf3(int MB, int NB) {
+  if (NB == 1) {
+    switch (MB) {
+      case 1: return conv_gemm_bf3_kernel<1, 1>;
+      case 2: return conv_gemm_bf3_kernel<2, 1>;
+      case 4: return conv_gemm_bf3_kernel<4, 1>;
+      case 8: return conv_gemm_bf3_kernel<8, 1>;
+    }
+  } else if (NB == 2) {
+    switch (MB) {
+      case 1: return conv_gemm_bf3_kernel<1, 2>;
+      case 2: return conv_gemm_bf3_kernel<2, 2>;
+      case 4: return conv_gemm_bf3_kernel<4, 2>;
+    }
+  }
+  return nullptr;
+}
+
 int fst_check_plan(const int32_t* ph, int plan_len, int M, const char* who) {
   FST_REQUIRE(ph != nullptr && plan_len >= FST_PLAN_HDR, "%s: plan missing or shorter than its header", who);
   FST_REQUIRE(plan_expected_len(ph) == plan_len, "%s: plan length %d != expected %d", who, plan_len,
@@ -614,6 +807,8 @@ int fst_check_plan(const int32_t* ph, int plan_len, int M, const char* who) {
       FST_REQUIRE(e[0] >= 0 && e[1] <= pv.ntaps && e[2] >= 0, "%s: bad tap range at (g=%d,q=%d)", who, g, q);
       const int nrec = e[1] > e[0] ? (e[1] - e[0]) * (((c[2] + 1) & ~1) / 2) : 0;
       FST_REQUIRE(e[2] + nrec <= pv.total_records, "%s: record overflow at (g=%d,q=%d)", who, g, q);
+      FST_REQUIRE(e[3] >= 0 && e[3] + (e[1] > e[0] ? e[1] - e[0] : 0) <= pv.n_stages, "%s: stage overflow at (g=%d,q=%d)",
+                  who, g, q);
     }
   }
   return 0;
@@ -642,7 +837,14 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   const bool shifts4 = pv.pad_left % 4 == 0 && (pv.ntaps == 1 || pv.dil % 4 == 0);   // every tap shift ≡ 0 (mod 4)
   const bool vec = pipe && L % 4 == 0 && shifts4 && x0_bs % 4 == 0 && al16(x0) &&
                    (x1 == nullptr || (x1_bs % 4 == 0 && al16(x1)));
-  conv_gemm_fn fn = pipe ? pick_conv_gemm_pipe(pv.MB, nb_cfg, vec) : pick_conv_gemm(pv.MB, nb_cfg);
+  const bool bf3 = (flags & FST_GEMM_BF16X3) != 0;
+  if (bf3) {
+    FST_REQUIRE(pipe, "fst_conv_gemm: FST_GEMM_BF16X3 needs a pipelined plan (single-tap stages of <= 16 channels) and NB <= 2");
+    FST_REQUIRE(L % 4 == 0 && x0_bs % 4 == 0 && al16(x0) && (x1 == nullptr || (x1_bs % 4 == 0 && al16(x1))),
+                "fst_conv_gemm: FST_GEMM_BF16X3 needs L %% 4 == 0 and 16-byte aligned activations (L=%d)", L);
+  }
+  conv_gemm_fn fn = bf3 ? pick_conv_gemm_bf3(pv.MB, nb_cfg)
+                        : (pipe ? pick_conv_gemm_pipe(pv.MB, nb_cfg, vec) : pick_conv_gemm(pv.MB, nb_cfg));
   FST_REQUIRE(fn != nullptr, "fst_conv_gemm: no kernel for MB=%d NB=%d", pv.MB, nb_cfg);
   const int TILE_N = 128 * nb_cfg;
 
@@ -682,7 +884,8 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   const size_t epi_bytes = 4 * 32 * 36 * sizeof(float);     // one transpose tile per wave
   if (pipe) {
     p.mg_per_wg = 1;
-    lds_bytes = 2 * ((size_t)(PIPE_C / 2) * pv.MB * 64 + (size_t)PIPE_C * TILE_N) * sizeof(float);
+    lds_bytes = bf3 ? 2 * ((size_t)pv.MB * 2048 + 2 * (size_t)PIPE_C * (2 * TILE_N + 64))
+                    : 2 * ((size_t)(PIPE_C / 2) * pv.MB * 64 + (size_t)PIPE_C * TILE_N) * sizeof(float);
     p.epi_lds_off = 0;                                       // the staging buffers are dead after the last barrier
     if (lds_bytes < epi_bytes) lds_bytes = epi_bytes;
   } else {
@@ -1133,8 +1336,45 @@ __global__ __launch_bounds__(256) void pack_kernel(PackParams p, const int32_t* 
   }
 }
 
+// Split-bf16 image for conv_gemm_bf3_kernel: one thread per (tap of the entry, 32-row block, lane) writes the
+// lane's 8 hi parts and 8 lo parts (2 x 16 bytes).
+__global__ __launch_bounds__(256) void pack_bf3_kernel(PackParams p, const int32_t* __restrict__ plan) {
+  const PlanView pv = plan_view(plan);
+  const int gq = blockIdx.y + p.g_begin * pv.n_chunks;
+  const int g = gq / pv.n_chunks, q = gq - g * pv.n_chunks;
+  const int32_t* e = pv.mg + 4 * gq;
+  const int32_t* c = pv.chunk + 4 * q;
+  const int lo = e[0], hi = e[1];
+  if (hi <= lo) return;
+  const int MB = pv.MB, s = c[0];
+  const int total = (hi - lo) * MB * 64;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int lane = idx & 63;
+    const int mb = (idx >> 6) % MB;
+    const int tapi = (idx >> 6) / MB;
+    const int m = (g * MB + mb) * 32 + (lane & 31);
+    const bool row_ok = m >= p.row_base && m < p.M;
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int cl = 8 * (lane >> 5) + 2 * j + k;
+        const long long woff = p.src[s].off0 + (long long)(m - p.row_base) * p.src[s].sm +
+                               (long long)(c[1] + cl) * p.src[s].sc + (long long)(lo + tapi) * p.src[s].st;
+        v[k] = (row_ok && cl < c[2]) ? p.src[s].w[woff] : 0.f;
+      }
+      split_bf16_pair(v[0], v[1], hh[j], ll[j]);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(p.a) + ((long long)(e[3] + tapi) * MB + mb) * 128 + lane;
+    dst[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+    dst[64] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+  }
+}
+
 static int launch_pack(const int32_t* plan_dev, const int32_t* plan_host, int plan_len, const PackParams& p0,
-                       const char* who, void* stream) {
+                       const char* who, void* stream, bool bf3 = false) {
   if (int rc = fst_check_plan(plan_host, plan_len, p0.M, who)) return rc;
   const PlanView pv = plan_view(plan_host);
   FST_REQUIRE(p0.g_begin >= 0 && p0.g_begin < p0.g_end && p0.g_end <= pv.n_mgroups && p0.row_base >= 0,
@@ -1153,8 +1393,14 @@ static int launch_pack(const int32_t* plan_dev, const int32_t* plan_host, int pl
   if (bx > 1024) bx = 1024;
   PackParams p = p0;
   p.plan = plan_dev;
-  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)(pv.n_chunks * (p0.g_end - p0.g_begin))), dim3(256), 0,
-                     (hipStream_t)stream, p, plan_dev);
+  if (bf3) {
+    FST_REQUIRE(plan_is_pipeable(pv), "%s: the split-bf16 image needs single-tap stages of <= %d channels", who, PIPE_C);
+    hipLaunchKernelGGL(pack_bf3_kernel, dim3(1, (unsigned)(pv.n_chunks * (p0.g_end - p0.g_begin))), dim3(256), 0,
+                       (hipStream_t)stream, p, plan_dev);
+  } else {
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)(pv.n_chunks * (p0.g_end - p0.g_begin))), dim3(256), 0,
+                       (hipStream_t)stream, p, plan_dev);
+  }
   FST_LAUNCH_CHECK();
   return 0;
 }
@@ -1173,6 +1419,22 @@ extern "C" int fst_pack_weights(const int32_t* plan_dev, const int32_t* plan_hos
     for (int q = 0; q < pv.n_chunks; ++q)
       FST_REQUIRE(pv.chunk[4 * q] == 0 || (src1 && src1->w), "fst_pack_weights: plan reads input 1 but src1 is null");
   return launch_pack(plan_dev, plan_host, plan_len, p, "fst_pack_weights", stream);
+}
+
+extern "C" int fst_pack_weights_bf16x3(const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
+                                       const fst_wsrc* src0, const fst_wsrc* src1, int M, int g_begin, int g_end,
+                                       int row_base, void* a_image, void* stream) {
+  FST_REQUIRE(plan_dev && plan_host && src0 && src0->w && a_image, "fst_pack_weights_bf16x3: null operand");
+  PackParams p = {};
+  p.src[0] = *src0;
+  if (src1) p.src[1] = *src1;
+  p.a = static_cast<float*>(a_image); p.M = M; p.unpack = 0;
+  p.g_begin = g_begin; p.g_end = g_end < 0 ? (plan_len >= FST_PLAN_HDR ? plan_host[1] : 0) : g_end; p.row_base = row_base;
+  const PlanView pv = plan_view(plan_host);
+  if (plan_len >= FST_PLAN_HDR)
+    for (int q = 0; q < pv.n_chunks; ++q)
+      FST_REQUIRE(pv.chunk[4 * q] == 0 || (src1 && src1->w), "fst_pack_weights_bf16x3: plan reads input 1 but src1 is null");
+  return launch_pack(plan_dev, plan_host, plan_len, p, "fst_pack_weights_bf16x3", stream, true);
 }
 
 extern "C" int fst_unpack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len, const float* a_packed,

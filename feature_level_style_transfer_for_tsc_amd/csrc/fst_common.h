@@ -7,7 +7,7 @@
 
 #include "../../include/fst_hip.h"
 
-#define FST_PLAN_HDR FST_PLAN_HEADER   // 16 ints; see plan.py (fields 0..9 used)
+#define FST_PLAN_HDR FST_PLAN_HEADER   // 16 ints; see plan.py (fields 0..10 used)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,16 +32,16 @@ void fst_set_error(const char* fmt, ...);
   } while (0)
 
 struct PlanView {
-  int n_chunks, n_mgroups, MB, ntaps, dil, pad_left, chunk_cap, total_records, n_items, items_per_wg;
+  int n_chunks, n_mgroups, MB, ntaps, dil, pad_left, chunk_cap, total_records, n_items, items_per_wg, n_stages;
   const int32_t* chunk;  // [n_chunks][4]  src, c_begin, c_count, 0
-  const int32_t* mg;     // [n_mgroups][n_chunks][4]  tap_lo, tap_hi, rec_off, 0
+  const int32_t* mg;     // [n_mgroups][n_chunks][4]  tap_lo, tap_hi, rec_off, stage_off
   const int32_t* item;   // [n_items][4]  g, q, row_block, 0   (q < 0: padding)
 };
 
 static inline __host__ __device__ PlanView plan_view(const int32_t* p) {
   PlanView v;
   v.n_chunks = p[0]; v.n_mgroups = p[1]; v.MB = p[2]; v.ntaps = p[3]; v.dil = p[4]; v.pad_left = p[5];
-  v.chunk_cap = p[6]; v.total_records = p[7]; v.n_items = p[8]; v.items_per_wg = p[9];
+  v.chunk_cap = p[6]; v.total_records = p[7]; v.n_items = p[8]; v.items_per_wg = p[9]; v.n_stages = p[10];
   v.chunk = p + FST_PLAN_HDR;
   v.mg = v.chunk + 4 * v.n_chunks;
   v.item = v.mg + 4 * v.n_chunks * v.n_mgroups;

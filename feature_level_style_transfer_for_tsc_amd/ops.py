@@ -6,6 +6,7 @@ device memory and the autograd graph only.  No op has a CPU implementation.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -15,6 +16,10 @@ from ._lib import WSrc, check, ptr, stream_ptr
 from .plan import Plan, Segment, build_plan, pick_mb
 
 EPI_RELU, EPI_ACC2, EPI_ATOMIC, EPI_ACC1 = 1, 2, 4, 8
+GEMM_BF16X3 = 16
+# Arithmetic of the pipelined forward / data-gradient GEMMs: "bf16x3" = split-bf16 operands on the bf16 matrix cores
+# (hi*hi + hi*lo + lo*hi, fp32 accumulate, ~5e-6 of the output scale); "f32" = exact f32 MFMA everywhere.
+MATH = os.environ.get("FST_MATH", "bf16x3")
 LDS_BUDGET = 96 * 1024
 LDS_MULTI_CHUNK = 44 * 1024
 PIPE_C = 16            # channels per stage of the pipelined conv kernel (csrc/conv_engine.hip)
@@ -61,6 +66,12 @@ def _vec16(plan: Plan, L: int, *tensors) -> bool:
         if t is not None:
             ok = ok and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
     return ok
+
+
+def bf3_ok(plan: Plan, L: int) -> bool:
+    """Whether a conv_gemm launch of ``plan`` at sequence length L takes the split-bf16 path (activations of a
+    multiple-of-4 length are 16-byte aligned by construction: channel stride L, batch stride C*L)."""
+    return MATH == "bf16x3" and plan.pipeable and L % 4 == 0
 
 
 def _plan_macs_per_step(plan: Plan, M: int) -> int:
@@ -133,24 +144,25 @@ class pack_cache:
 
 
 def pack_weights(plan: Plan, M: int, w0: Tensor, s0: Tuple[int, int, int, int], w1: Optional[Tensor] = None,
-                 s1: Tuple[int, int, int, int] = (0, 0, 0, 0), parts=None) -> Tensor:
+                 s1: Tuple[int, int, int, int] = (0, 0, 0, 0), parts=None, bf3: bool = False) -> Tensor:
     """Pack weights for ``plan``.  ``parts`` (optional) fills different M-group ranges from different weight
-    tensors: a list of (g_begin, g_end, row_base, row_end, w, strides)."""
+    tensors: a list of (g_begin, g_end, row_base, row_end, w, strides).  ``bf3``: the split-bf16 image."""
     if _PACK_CACHE is not None:
-        key = (id(plan), M, w0.data_ptr(), w0._version, s0, None if w1 is None else (w1.data_ptr(), w1._version), s1,
+        key = (id(plan), bf3, M, w0.data_ptr(), w0._version, s0, None if w1 is None else (w1.data_ptr(), w1._version), s1,
                None if parts is None else tuple((p[0], p[1], p[2], p[3], p[4].data_ptr(), p[4]._version, p[5]) for p in parts))
         hit = _PACK_CACHE.get(key)
         if hit is not None:
             return hit[0]
-        a = _pack_weights(plan, M, w0, s0, w1, s1, parts)
+        a = _pack_weights(plan, M, w0, s0, w1, s1, parts, bf3)
         _PACK_CACHE[key] = (a, w0, w1, plan, parts)
         return a
-    return _pack_weights(plan, M, w0, s0, w1, s1, parts)
+    return _pack_weights(plan, M, w0, s0, w1, s1, parts, bf3)
 
 
-def _pack_weights(plan: Plan, M: int, w0: Tensor, s0, w1: Optional[Tensor], s1, parts=None) -> Tensor:
+def _pack_weights(plan: Plan, M: int, w0: Tensor, s0, w1: Optional[Tensor], s1, parts=None, bf3: bool = False) -> Tensor:
     lib = _lib.load()
-    a = torch.empty(plan.packed_floats, device=w0.device, dtype=torch.float32)
+    a = torch.empty(plan.packed_floats_bf3 if bf3 else plan.packed_floats, device=w0.device, dtype=torch.float32)
+    fn, who = (lib.fst_pack_weights_bf16x3, "fst_pack_weights_bf16x3") if bf3 else (lib.fst_pack_weights, "fst_pack_weights")
     second = (w1, s1)
     if parts is None:
         parts = [(0, -1, 0, M, w0, s0)]
@@ -159,9 +171,8 @@ def _pack_weights(plan: Plan, M: int, w0: Tensor, s0, w1: Optional[Tensor], s1, 
     for (g0, g1, row_base, row_end, w, sw) in parts:
         src0 = _wsrc(w, *sw)
         src1 = _wsrc(second[0], *second[1]) if second[0] is not None else None
-        check(lib.fst_pack_weights(ptr(plan.dev(w0.device)), plan.host_ptr(), plan.length, ctypes.byref(src0),
-                                   ctypes.byref(src1) if src1 is not None else None, row_end, g0, g1, row_base, ptr(a),
-                                   stream_ptr()), "fst_pack_weights")
+        check(fn(ptr(plan.dev(w0.device)), plan.host_ptr(), plan.length, ctypes.byref(src0),
+                 ctypes.byref(src1) if src1 is not None else None, row_end, g0, g1, row_base, ptr(a), stream_ptr()), who)
     return a
 
 
@@ -173,8 +184,10 @@ def unpack_weights(plan: Plan, M: int, a: Tensor, dw0: Tensor, s0, dw1: Optional
 
 def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Optional[Tensor], B: int, L: int, M: int,
               y: Optional[Tensor], res: Optional[Tensor] = None, y2: Optional[Tensor] = None, msplit: Optional[int] = None,
-              nb: int = 1, ksplit: int = 1, flags: int = 0, m2_start: Optional[int] = None) -> None:
+              nb: int = 1, ksplit: int = 1, flags: int = 0, m2_start: Optional[int] = None, bf3: bool = False) -> None:
     lib = _lib.load()
+    if bf3:
+        flags |= GEMM_BF16X3
     msplit = M if msplit is None else msplit
     m2_start = msplit if m2_start is None else m2_start
     x0_bs, _ = _ncl(x0, "x0")
@@ -187,7 +200,9 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
                             plan.length, ptr(bias), ptr(y), y_bs, ptr(res), res_bs, ptr(y2), y2_bs, msplit, m2_start, B, L,
                             M, nb, ksplit, flags, stream_ptr()), "fst_conv_gemm")
     if t0 is not None:
-        if plan.pipeable and nb <= 2:
+        if bf3:
+            key = f"conv_gemm_bf3_kernel<{plan.MB}, {nb}>"
+        elif plan.pipeable and nb <= 2:
             key = f"conv_gemm_pipe_kernel<{plan.MB}, {nb}, {'true' if _vec16(plan, L, x0, x1) else 'false'}>"
         else:
             key = f"conv_gemm_kernel<{plan.MB}, {nb}>"
@@ -369,10 +384,11 @@ class ConvSpec:
         windowed = self.C0 if self._windowed(max(self.C0, self.C1)) else 0
         nb = self.nb_for(B, L, self.mb, windowed, self._halo())
         plan = self.fwd_plan(nb)
-        a = pack_weights(plan, self.M, w0, self.s_w0(), w1, self.s_w1())
+        bf3 = bf3_ok(plan, L)
+        a = pack_weights(plan, self.M, w0, self.s_w0(), w1, self.s_w1(), bf3=bf3)
         if y is None and (msplit is None or msplit > 0):
             y = torch.empty(B, self.M if msplit is None else msplit, L, device=x0.device, dtype=torch.float32)
-        conv_gemm(plan, a, x0, x1, bias, B, L, self.M, y, res, y2, msplit, nb=nb, flags=flags)
+        conv_gemm(plan, a, x0, x1, bias, B, L, self.M, y, res, y2, msplit, nb=nb, flags=flags, bf3=bf3)
         return y
 
     def grad_x0(self, dy: Tensor, w0: Tensor, out: Optional[Tensor] = None, res: Optional[Tensor] = None,
@@ -382,10 +398,11 @@ class ConvSpec:
         windowed = self.M if self._windowed(self.M) else 0
         nb = self.nb_for(B, L, mb, windowed, self._halo())
         plan = self.dx0_plan(nb)
-        a = pack_weights(plan, self.C0, w0, self.s_w0_T())
+        bf3 = bf3_ok(plan, L)
+        a = pack_weights(plan, self.C0, w0, self.s_w0_T(), bf3=bf3)
         if out is None:
             out = torch.empty(B, self.C0, L, device=dy.device, dtype=torch.float32)
-        conv_gemm(plan, a, dy, None, None, B, L, self.C0, out, res, nb=nb, flags=flags)
+        conv_gemm(plan, a, dy, None, None, B, L, self.C0, out, res, nb=nb, flags=flags, bf3=bf3)
         return out
 
     def dx01_plan(self, nb: int) -> Plan:
@@ -410,21 +427,24 @@ class ConvSpec:
         plan = self.dx01_plan(nb)
         R = plan.M - self.C1
         n_g0 = R // (mb * 32)
+        bf3 = bf3_ok(plan, L)
         a = pack_weights(plan, plan.M, w0, self.s_w0_T(), parts=[(0, n_g0, 0, self.C0, w0, self.s_w0_T()),
-                                                                 (n_g0, plan.n_mgroups, R, plan.M, w1, self.s_w1_T())])
+                                                                 (n_g0, plan.n_mgroups, R, plan.M, w1, self.s_w1_T())],
+                         bf3=bf3)
         out = torch.empty(B, self.C0, L, device=dy.device, dtype=torch.float32)
         conv_gemm(plan, a, dy, None, None, B, L, plan.M, out, res0, acc1, msplit=self.C0, nb=nb, flags=EPI_ACC2,
-                  m2_start=R)
+                  m2_start=R, bf3=bf3)
         return out
 
     def grad_x1(self, dy: Tensor, w1: Tensor, out: Optional[Tensor] = None, flags: int = 0) -> Tensor:
         B, L = dy.size(0), dy.size(2)
         nb = self.nb_for(B, L, pick_mb(self.C1), 0, 0)
         plan = self.dx1_plan(nb)
-        a = pack_weights(plan, self.C1, w1, self.s_w1_T())
+        bf3 = bf3_ok(plan, L)
+        a = pack_weights(plan, self.C1, w1, self.s_w1_T(), bf3=bf3)
         if out is None:
             out = torch.empty(B, self.C1, L, device=dy.device, dtype=torch.float32)
-        conv_gemm(plan, a, dy, None, None, B, L, self.C1, out, nb=nb, flags=flags)
+        conv_gemm(plan, a, dy, None, None, B, L, self.C1, out, nb=nb, flags=flags, bf3=bf3)
         return out
 
     def grad_w(self, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor] = None,
@@ -649,11 +669,15 @@ class WNFn(torch.autograd.Function):
             # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
             dacts = torch.empty(B, n, L, device=dev, dtype=torch.float32)
             if last:
-                a_pk = pack_weights(S.rs_T_last, n, rs_w[i], (0, 1, n, 0))
-                conv_gemm(S.rs_T_last, a_pk, d_out, None, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0))
+                bf3 = bf3_ok(S.rs_T_last, L)
+                a_pk = pack_weights(S.rs_T_last, n, rs_w[i], (0, 1, n, 0), bf3=bf3)
+                conv_gemm(S.rs_T_last, a_pk, d_out, None, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0),
+                          bf3=bf3)
             else:
-                a_pk = pack_weights(S.rs_T, n, rs_w[i], (0, 1, n, 0), rs_w[i], (n * n, 1, n, 0))
-                conv_gemm(S.rs_T, a_pk, d_a, d_out, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0))
+                bf3 = bf3_ok(S.rs_T, L)
+                a_pk = pack_weights(S.rs_T, n, rs_w[i], (0, 1, n, 0), rs_w[i], (n * n, 1, n, 0), bf3=bf3)
+                conv_gemm(S.rs_T, a_pk, d_a, d_out, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0),
+                          bf3=bf3)
             if need_w:
                 if last:
                     d_rs_w[i], _ = S.rs[i].grad_w(acts_list[i], None, d_out)
@@ -802,10 +826,11 @@ def _fixed_matmul(x: Tensor, R: Tensor, M: int, K: int, N: int) -> Tensor:
     if key not in _matmul_plans:
         _matmul_plans[key] = build_plan(M, [Segment(0, K, 0, 1)], 1, 1, 0, chunk_c=PIPE_C)
     plan = _matmul_plans[key]
-    a = pack_weights(plan, M, x, (0, K, 1, 0))
+    bf3 = bf3_ok(plan, N)
+    a = pack_weights(plan, M, x, (0, K, 1, 0), bf3=bf3)
     n_tiles = (N + 127) // 128
     ksplit = max(1, min(plan.n_chunks, 512 // max(1, n_tiles * plan.n_mgroups)))
     y = torch.zeros(1, M, N, device=x.device, dtype=torch.float32)
     conv_gemm(plan, a, R.view(1, K, N), None, None, 1, N, M, y, nb=1, ksplit=ksplit,
-              flags=EPI_ATOMIC if ksplit > 1 else 0)
+              flags=EPI_ATOMIC if ksplit > 1 else 0, bf3=bf3)
     return y.view(M, N)

@@ -16,9 +16,13 @@ prime kernel, so masked taps are never multiplied (57 % of a dense Kmax conv's M
 Table layout (int32), mirrored by ``plan_view`` in csrc/fst_common.h::
 
     [0] n_chunks [1] n_mgroups [2] MB [3] ntaps [4] dil [5] pad_left [6] chunk_cap [7] total_records
-    [8] n_items  [9] items_per_wg  [10..15] reserved
+    [8] n_items  [9] items_per_wg  [10] n_stages  [11..15] reserved
     chunk table   n_chunks × (src, c_begin, c_count, 0)
-    (g,q) table   n_mgroups × n_chunks × (tap_lo, tap_hi, record_offset, 0)
+    (g,q) table   n_mgroups × n_chunks × (tap_lo, tap_hi, record_offset, stage_offset)
+
+``stage_offset`` / ``n_stages`` address the split-bf16 weight image of the pipelined kernel: one stage = one live
+(M-group, chunk, tap) triple = one 16-deep ``v_mfma_f32_32x32x16_bf16`` k-step, stored per 32-row block as
+64 lanes × 8 bf16 "hi" parts followed by 64 lanes × 8 bf16 "lo" parts (w ≈ hi + lo, each rounded to nearest).
     item table    n_items × (g, q, row_block, 0)          q = −1 marks padding
 """
 from __future__ import annotations
@@ -54,11 +58,17 @@ class Plan:
     pad_left: int
     total_records: int
     chunk_cap: int
+    n_stages: int = 0          # live (M-group, chunk, tap) triples = 16-deep k-steps of the split-bf16 kernel
     _dev: Dict[str, object] = field(default_factory=dict, repr=False)
 
     @property
     def packed_floats(self) -> int:
         return self.total_records * self.MB * 64
+
+    @property
+    def packed_floats_bf3(self) -> int:
+        """Size (in 4-byte words) of the split-bf16 image: per stage and 32-row block 64 lanes x (8 hi + 8 lo) bf16."""
+        return self.n_stages * self.MB * 512
 
     @property
     def length(self) -> int:
@@ -132,6 +142,7 @@ def build_plan(M: int, segments: Sequence[Segment], ntaps: int, dil: int = 1, pa
 
     entries = np.zeros((n_mgroups, n_chunks, 4), dtype=np.int32)
     rec = 0
+    stage = 0
     items: List[Tuple[int, int, int, int]] = []
     for g in range(n_mgroups):
         n_before = len(items)
@@ -142,11 +153,12 @@ def build_plan(M: int, segments: Sequence[Segment], ntaps: int, dil: int = 1, pa
                 lo_q, hi_q = max(lo_q, min(r[0] for r in cl)), min(hi_q, max(r[1] for r in cl))
             lo_q, hi_q = max(lo_q, group_live[g][0]), min(hi_q, group_live[g][1])
             if hi_q <= lo_q:
-                entries[g, q] = (0, 0, rec, 0)
+                entries[g, q] = (0, 0, rec, stage)
                 continue
             c_pad = (cnt + 1) & ~1
-            entries[g, q] = (lo_q, hi_q, rec, 0)
+            entries[g, q] = (lo_q, hi_q, rec, stage)
             rec += (hi_q - lo_q) * (c_pad // 2)
+            stage += hi_q - lo_q
             if with_items:
                 n_rb = ((hi_q - lo_q) * c_pad + 31) // 32
                 if hi_q > lo_q + 1:                               # windowed chunk: its own workgroups
@@ -162,13 +174,13 @@ def build_plan(M: int, segments: Sequence[Segment], ntaps: int, dil: int = 1, pa
     total_records = rec
 
     table = np.zeros(HDR + 4 * n_chunks + 4 * n_chunks * n_mgroups + 4 * len(items), dtype=np.int32)
-    table[:10] = (n_chunks, n_mgroups, MB, ntaps, dil, pad_left, chunk_cap, total_records, len(items), WG_ITEMS)
+    table[:11] = (n_chunks, n_mgroups, MB, ntaps, dil, pad_left, chunk_cap, total_records, len(items), WG_ITEMS, stage)
     table[HDR: HDR + 4 * n_chunks] = np.array([(c[0], c[1], c[2], 0) for c in chunks], dtype=np.int32).ravel()
     o = HDR + 4 * n_chunks
     table[o: o + entries.size] = entries.ravel()
     if items:
         table[o + entries.size:] = np.array(items, dtype=np.int32).ravel()
-    return Plan(table, M, MB, n_mgroups, n_chunks, ntaps, dil, pad_left, total_records, chunk_cap)
+    return Plan(table, M, MB, n_mgroups, n_chunks, ntaps, dil, pad_left, total_records, chunk_cap, stage)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 1
+#define FST_ABI_VERSION 2
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -36,9 +36,9 @@ const char* fst_last_error(void);
  *
  *   plan[0..15]  header: n_chunks, n_mgroups, MB (32-row blocks per M-group), ntaps, dil, pad_left,
  *                        chunk_cap (max padded channels per chunk, even), total_records,
- *                        n_items, items_per_wg, 6 reserved (0)
+ *                        n_items, items_per_wg, n_stages, 5 reserved (0)
  *   plan[16 + 4*q ...]                 chunk q:        src (0|1), c_begin, c_count, 0
- *   plan[16 + 4*n_chunks + 4*(g*n_chunks+q) ...]  (g,q): tap_lo, tap_hi, record_offset, 0
+ *   plan[16 + 4*n_chunks + 4*(g*n_chunks+q) ...]  (g,q): tap_lo, tap_hi, record_offset, stage_offset
  *   plan[16 + 4*n_chunks*(1+n_mgroups) + 4*i ...] item i (weight-gradient plans only):
  *                                                       g, q, row_block, 0      (q < 0: padding item)
  *
@@ -64,6 +64,16 @@ int fst_pack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan
                      int M, int g_begin, int g_end /* M-group range, -1 = all */, int row_base /* view row = m - row_base */,
                      float* a_packed, void* stream);
 
+/* Same as fst_pack_weights, into the split-bf16 image the FST_GEMM_BF16X3 path of fst_conv_gemm reads
+ * (plan.n_stages * MB * 2048 bytes): every weight w is stored as two round-to-nearest bf16 parts,
+ * hi = bf16(w) and lo = bf16(w - hi); stage s (= one live (M-group, chunk, tap) triple, 16 channels deep),
+ * 32-row block mb: 64 lanes x 8 hi parts, then 64 lanes x 8 lo parts, lane l = row l&31, channels 8*(l>>5)+0..7
+ * — the A-operand fragments of v_mfma_f32_32x32x16_bf16.  Only for plans made of single-tap stages of at
+ * most 16 channels (the pipelined kernel's plans). */
+int fst_pack_weights_bf16x3(const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
+                            const fst_wsrc* src0_host, const fst_wsrc* src1_host,
+                            int M, int g_begin, int g_end, int row_base, void* a_image, void* stream);
+
 /* Inverse of fst_pack_weights for weight gradients: scatter a packed gradient back to PyTorch
  * layout (dw0/dw1 must be zero-filled by the caller when the plan does not cover every tap). */
 int fst_unpack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
@@ -81,11 +91,16 @@ int fst_mask_taps(float* w, const int32_t* live_lo, const int32_t* live_hi, int 
  * (accumulated if FST_EPI_ACC2).  Replaces F.conv1d/nn.Conv1d at OS_CNN/OS_CNN.py:71,164 and
  * Simplified_NF_WaveGlow.py:36,41,103,107,112,116,123; with transposed packing it is also the
  * data-gradient conv of every one of those.
- *   flags: FST_EPI_RELU, FST_EPI_ACC2, FST_EPI_ATOMIC (ksplit>1; y must be pre-initialised) */
-#define FST_EPI_RELU   1
-#define FST_EPI_ACC2   2
-#define FST_EPI_ATOMIC 4
-#define FST_EPI_ACC1   8
+ *   flags: FST_EPI_RELU, FST_EPI_ACC2, FST_EPI_ATOMIC (ksplit>1; y must be pre-initialised);
+ *   FST_GEMM_BF16X3: a_packed is the image written by fst_pack_weights_bf16x3 and every product is formed as
+ *   hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (both operands split into two
+ *   round-to-nearest bf16 parts; relative error of a product <= 3*2^-18, measured 5e-6 of the output scale)
+ *   — about 5x the f32 MFMA rate.  Needs a pipelined plan, L % 4 == 0 and 16-byte aligned activations. */
+#define FST_EPI_RELU    1
+#define FST_EPI_ACC2    2
+#define FST_EPI_ATOMIC  4
+#define FST_EPI_ACC1    8
+#define FST_GEMM_BF16X3 16
 int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs,
                   const float* a_packed, const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
                   const float* bias,
