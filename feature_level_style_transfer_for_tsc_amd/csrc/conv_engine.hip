@@ -540,24 +540,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_pipe_kernel(ConvGemmParams p
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient on the bf16 matrix cores with split operands ("bf16x3").
 //
-// Same plans, stage structure, pipeline and epilogue as conv_gemm_pipe_kernel; the product of a stage is formed
-// as  hi(A)·hi(B) + hi(A)·lo(B) + lo(A)·hi(B)  by three v_mfma_f32_32x32x16_bf16 (fp32 accumulate), where
+// Same plans, stages and epilogue as conv_gemm_pipe_kernel; the product of a stage is formed as
+// hi(A)·hi(B) + hi(A)·lo(B) + lo(A)·hi(B) by three v_mfma_f32_32x32x16_bf16 (fp32 accumulate), where
 // v = hi + lo + O(2^-18 |v|), hi = bf16_rne(v), lo = bf16_rne(v − hi).  One stage (≤ 16 channels of one tap) is
-// exactly one 16-deep k-step: 3·MB·NB MFMAs of 32 cycles instead of 8·MB·NB of 64.
-//   A: the image written by fst_pack_weights_bf16x3 — per stage and 32-row block 1 KiB of hi fragments then
-//      1 KiB of lo fragments, copied to LDS verbatim and read back with one ds_read_b128 per fragment.
-//   B: the [16 channels][TILE_N] tile of shifted input rows is fetched as 16-byte loads at 16-byte aligned
-//      times (plus the following 16 bytes when the tap shift is not a multiple of 4 samples; the sub-shift is
-//      wave-uniform), split into hi / lo on the way into LDS (two [16][TILE_N] bf16 images, row stride
-//      2·TILE_N + 64 bytes) and read as MFMA B fragments (k-strided) with ds_read_b64_tr_b16: a 32-lane half
-//      reads 4 rows × 64 contiguous bytes that fall into 4 disjoint bank groups.
+// exactly one 16-deep k-step: 3·MB·NB MFMAs of 32 cycles — far shorter than a global round trip, so operands
+// arrive through a 3-slot LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, two stages
+// in flight while one is multiplied; one raw s_barrier per stage behind a counted vmcnt).
+//   A: the image written by fst_pack_weights_bf16x3 (per stage and 32-row block 1 KiB of hi fragments, 1 KiB of
+//      lo fragments), copied verbatim, read back with one ds_read_b128 per fragment.
+//   B: raw fp32 input samples of the 16-byte aligned window [t4, t4 + TILE_N + 4) of the stage's 16 channels,
+//      t4 = tap-shifted tile start rounded down to 4 samples, stored as 1-KiB sub-tiles of 8 channels × 32
+//      samples (one wave-instruction each; out-of-range pieces are fetched from a 16-byte zero block behind
+//      the A image).  A wave reads its MFMA B fragment (8 channels of one time sample per lane) with eight
+//      conflict-free ds_read_b32 at column n + (shift mod 4) — the tap's sub-shift costs nothing — and splits it
+//      into hi / lo in registers.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-#define FST_LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define FST_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define FST_LDS_VOID(p) ((__attribute__((address_space(3))) void*)(p))
 
 // two floats -> (hi pair, lo pair), each a dword of two round-to-nearest bf16 (first element in the low half)
 __device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, unsigned& lo) {
@@ -567,16 +570,28 @@ __device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& hi, 
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Diagnostic builds only (tools/build_exp.sh): FST_EXP is a bit mask that removes one cost at a time from the
+// bf3 kernel (wrong results, timing only): 1 no MFMAs, 2 no B loads, 8 no hi/lo split, 16 no A loads.
+#ifndef FST_EXP
+#define FST_EXP 0
+#endif
+
 template <int MB, int NB>
 __global__ __launch_bounds__(256, 2) void conv_gemm_bf3_kernel(ConvGemmParams p, const int32_t* __restrict__ plan) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int TILE_N = 128 * NB;
-  constexpr int RS = 2 * TILE_N + 64;                  // bytes per image row
+  constexpr int NBLK = TILE_N / 32 + 1;               // 32-sample column blocks per row group (the last takes the sub-shift spill)
+  constexpr int GS = NBLK * 1024 + 128;               // bytes per 8-channel row group (+128: the two lane halves hit different banks)
   constexpr int A_BYTES = MB * 2048;
-  constexpr int STAGE_BYTES = A_BYTES + 2 * PIPE_C * RS;
-  constexpr int AV = (A_BYTES / 16 + 255) / 256;       // 16-byte pieces of A per thread per stage
-  constexpr int BR = PIPE_C * (TILE_N / 4) / 256;      // float4 rows of the B tile per thread per stage (NB=2: 4, NB=1: 2)
-  constexpr int LOG_N = NB == 1 ? 7 : 8;
+  constexpr int SLOT = A_BYTES + 2 * GS;
+  constexpr int NA = A_BYTES / 1024;                  // 1-KiB pieces of A per stage
+  constexpr int NI = NA + 2 * NBLK;                   // LDS-DMA wave-instructions per stage
+  constexpr int NPW = (NI + 3) / 4;                   // per wave (waves >= NI % 4 issue one fewer when NI % 4 != 0)
   char* const ldsb = reinterpret_cast<char*>(lds);
   const PlanView pv = plan_view(plan);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -589,71 +604,52 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf3_kernel(ConvGemmParams p,
   const int wave_n0 = wave * NB * 32;
   const int L = p.L;
   const int32_t* ent = pv.mg + 4 * (g * pv.n_chunks);
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const char* const zero16 = reinterpret_cast<const char*>(p.a) + (long long)pv.n_stages * A_BYTES;
 
   auto next_live = [&](int q) {
     while (q < q_end && ent[4 * q + 1] <= ent[4 * q]) ++q;
     return q;
   };
 
-  uint4 a_st[AV];
-  float4 b_lo[BR], b_hi4[BR];                          // aligned 16-byte pieces: [t, t+4) and [t+4, t+8)
-  int sub = 0;                                         // tap shift mod 4 of the stage in flight (uniform)
-  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // element (row, col4) of the [PIPE_C][TILE_N/4] float4 tile handled by this thread in pass i:
-  // row = row_u(i) + row_lane (row_u wave-uniform), column 4*(tid & (TILE_N/4-1))
-  const int row_lane = NB == 1 ? (lane >> 5) : 0;
-  const int col = (tid & (TILE_N / 4 - 1)) * 4;
-  auto fetch = [&](int q) {
+  // LDS-DMA of stage q into ring slot `slot`: piece idx = wave + 4*i; pieces [0, NA) are A, the rest B sub-tiles
+  auto issue = [&](int q, int slot) {
     const int32_t* c = pv.chunk + 4 * q;
     const int32_t* e = ent + 4 * q;
     const int c_count = c[2];
-    const uint4* asrc = reinterpret_cast<const uint4*>(p.a) + (long long)e[3] * (A_BYTES / 16);
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int idx = tid + 256 * i;
-      a_st[i] = (A_BYTES / 16 >= 256 * (i + 1) || idx < A_BYTES / 16) ? asrc[idx] : make_uint4(0, 0, 0, 0);
-    }
+    const char* asrc = reinterpret_cast<const char*>(p.a) + (long long)e[3] * A_BYTES;
     const float* xb = p.x[c[0]] + (long long)b * p.x_bs[c[0]] + (long long)c[1] * L;
     const int tbase = t0 - pv.pad_left + e[0] * pv.dil;
-    sub = tbase & 3;
-    const int t = (tbase & ~3) + col;                  // 16-byte aligned (L, strides and bases are multiples of 4 floats)
-    const bool ok0 = t >= 0 && t < L, ok1 = sub != 0 && t + 4 >= 0 && t + 4 < L;
+    const int t4 = tbase & ~3;
+    const bool spill = (tbase & 3) != 0;
+    char* const sl = ldsb + slot * SLOT;
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const int cc_u = (NB == 1 ? wave_s * 2 : wave_s) + (1024 >> LOG_N) * i;
-      const int cc = cc_u + row_lane;
-      const float* rp = xb + ((long long)cc_u * L + (long long)row_lane * L + t);
-      const bool row_ok = cc < c_count;
-      // unconditional loads from a safe address when masked: no exec-mask branch, no per-load wait
-      const float4 v0 = *reinterpret_cast<const float4*>((ok0 && row_ok) ? rp : p.x[0]);
-      const float4 v1 = *reinterpret_cast<const float4*>((ok1 && row_ok) ? rp + 4 : p.x[0]);
-      b_lo[i] = (ok0 && row_ok) ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
-      b_hi4[i] = (ok1 && row_ok) ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NPW; ++i) {
+      const int idx = wave_s + 4 * i;
+      if (idx >= NI) break;                            // wave-uniform
+      if (idx < NA) {
+        const char* src = (FST_EXP & 16) ? zero16 : asrc + idx * 1024 + lane * 16;
+        __builtin_amdgcn_global_load_lds(FST_GLOBAL_PTR(src), FST_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+      } else {
+        const int bi = idx - NA;
+        const int gq = bi >= NBLK ? 1 : 0, m = bi - gq * NBLK;
+        const int row = 8 * gq + (lane >> 3);
+        const int t = t4 + 32 * m + 4 * (lane & 7);
+        bool ok = row < c_count && t >= 0 && t < L;
+        if (m == NBLK - 1) ok = ok && spill && (lane & 7) == 0;
+        if (FST_EXP & 2) ok = false;
+        const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
+        __builtin_amdgcn_global_load_lds(FST_GLOBAL_PTR(src), FST_LDS_VOID(sl + A_BYTES + gq * GS + m * 1024), 16, 0, 0);
+      }
     }
   };
-  auto commit = [&](int buf) {
-    char* base = ldsb + buf * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < AV; ++i) {
-      const int idx = tid + 256 * i;
-      if (A_BYTES / 16 >= 256 * (i + 1) || idx < A_BYTES / 16) reinterpret_cast<uint4*>(base)[idx] = a_st[i];
-    }
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const float4 u = b_lo[i], w = b_hi4[i];
-      float e0, e1, e2, e3;
-      if (sub == 0) { e0 = u.x; e1 = u.y; e2 = u.z; e3 = u.w; }
-      else if (sub == 1) { e0 = u.y; e1 = u.z; e2 = u.w; e3 = w.x; }
-      else if (sub == 2) { e0 = u.z; e1 = u.w; e2 = w.x; e3 = w.y; }
-      else { e0 = u.w; e1 = w.x; e2 = w.y; e3 = w.z; }
-      unsigned h0, h1, l0, l1;
-      split_bf16_pair(e0, e1, h0, l0);
-      split_bf16_pair(e2, e3, h1, l1);
-      const int cc = (NB == 1 ? wave_s * 2 : wave_s) + (1024 >> LOG_N) * i + row_lane;
-      char* dst = base + A_BYTES + cc * RS + col * 2;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-      *reinterpret_cast<uint2*>(dst + PIPE_C * RS) = make_uint2(l0, l1);
-    }
+  // wait until at most `newer` stages issued after the one about to be read are still in flight
+  auto wait_stage = [&](int newer) {
+    constexpr int R = NI % 4;
+    const bool full = R == 0 || wave_s < R;            // this wave issues NPW pieces per stage, else NPW-1
+    if (newer == 0) wait_vmcnt<0>();
+    else if (newer == 1) { if (full) wait_vmcnt<NPW>(); else wait_vmcnt<NPW - 1>(); }
+    else { if (full) wait_vmcnt<2 * NPW>(); else wait_vmcnt<2 * NPW - 2>(); }
   };
 
   f32x16 acc[MB][NB];
@@ -664,52 +660,80 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf3_kernel(ConvGemmParams p,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
-  // per-lane byte offset of the transposed reads inside a B image: lane 4q+pp of the 16-lane group gr supplies
-  // row 8*half + q, columns wave_n0 + 16*(gr&1) + 4*pp .. +3 (ds_read_b64_tr_b16 hands lane i column i of the block)
-  const int gr = lane >> 4, u16 = lane & 15;
-  const int boff = (8 * half + (u16 >> 2)) * RS + 2 * (wave_n0 + 16 * (gr & 1) + 4 * (u16 & 3));
-
-  int q = next_live(q_begin);
-  if (q < q_end) {
-    fetch(q);
-    commit(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  while (q < q_end) {
-    const int qn = next_live(q + 1);
-    if (qn < q_end) fetch(qn);
-    const char* base = ldsb + buf * STAGE_BYTES;
-    const char* bh_img = base + A_BYTES + boff;
-    const char* bl_img = bh_img + PIPE_C * RS;
+  FST_SUMS;
+  FST_T(ts0);
+  int q0 = next_live(q_begin);
+  int q1 = q0 < q_end ? next_live(q0 + 1) : q_end;
+  if (q0 < q_end) issue(q0, 0);
+  if (q1 < q_end) issue(q1, 1);
+  int slot = 0;
+  FST_T(ts1);
+  FST_ACC(0, ts0, ts1);                                // prologue
+  while (q0 < q_end) {
+    FST_T(ta);
+    const int q2 = q1 < q_end ? next_live(q1 + 1) : q_end;
+    wait_stage(q1 < q_end ? 1 : 0);                    // stage q0 has landed (this wave's pieces) ...
+    FST_T(tb);
+    FST_ACC(1, ta, tb);                                // next_live + vmcnt wait
+    __builtin_amdgcn_s_barrier();                      // ... and everyone's; every wave is done reading the slot refilled next
+    FST_T(tc);
+    FST_ACC(2, tb, tc);                                // barrier
+    if (q2 < q_end) issue(q2, slot >= 1 ? slot - 1 : 2);
+    FST_T(td);
+    FST_ACC(3, tc, td);                                // LDS-DMA issue
+    const int sub = (t0 - pv.pad_left + ent[4 * q0] * pv.dil) & 3;
+    const char* base = ldsb + slot * SLOT;
     bf16x8 bh[NB], bl[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FST_LDS_PTR(s16x4, bh_img + nb * 64));
-      const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FST_LDS_PTR(s16x4, bh_img + nb * 64 + 4 * RS));
-      const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FST_LDS_PTR(s16x4, bl_img + nb * 64));
-      const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(FST_LDS_PTR(s16x4, bl_img + nb * 64 + 4 * RS));
-      bh[nb] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-      bl[nb] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+      const int colx = wave_n0 + nb * 32 + l31 + sub;
+      const char* bp = base + A_BYTES + half * GS + (colx >> 5) * 1024 + (colx & 31) * 4;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
+      u32x4 h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned hh, ll;
+        if (FST_EXP & 8) { hh = __float_as_uint(v[2 * j]); ll = __float_as_uint(v[2 * j + 1]); }
+        else split_bf16_pair(v[2 * j], v[2 * j + 1], hh, ll);
+        h[j] = hh; l[j] = ll;
+      }
+      bh[nb] = __builtin_bit_cast(bf16x8, h);
+      bl[nb] = __builtin_bit_cast(bf16x8, l);
     }
+#ifdef FST_STAMPS
+    asm volatile("" ::"v"(bh[0]), "v"(bl[0]), "v"(bh[NB - 1]), "v"(bl[NB - 1]));
+#endif
+    FST_T(te);
+    FST_ACC(4, td, te);                                // B fragments: LDS reads + split
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + mb * 2048 + lane * 16);
       const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
+        if (FST_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh[nb]), "v"(bl[nb])); continue; }
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nb], acc[mb][nb], 0, 0, 0);
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nb], acc[mb][nb], 0, 0, 0);
         acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nb], acc[mb][nb], 0, 0, 0);
       }
     }
-    if (qn < q_end) commit(buf ^ 1);
-    __syncthreads();
-    q = qn;
-    buf ^= 1;
+    FST_T(tf);
+    FST_ACC(5, te, tf);                                // A fragments + MFMAs (issue)
+    q0 = q1;
+    q1 = q2;
+    slot = slot == 2 ? 0 : slot + 1;
   }
-
+  FST_T(tg);
+  // all LDS-DMA has landed (the last wait was vmcnt(0)); the epilogue reuses the ring as transpose tiles once every
+  // wave is past its last fragment read
+  __syncthreads();
   conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0, lds);
+  FST_T(th);
+  FST_ACC(6, tg, th);                                  // epilogue
+  FST_ACC(7, ts0, th);                                 // whole wave
+  FST_FLUSH;
 }
 
 static bool plan_is_pipeable(const PlanView& pv) {
@@ -884,7 +908,7 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   const size_t epi_bytes = 4 * 32 * 36 * sizeof(float);     // one transpose tile per wave
   if (pipe) {
     p.mg_per_wg = 1;
-    lds_bytes = bf3 ? 2 * ((size_t)pv.MB * 2048 + 2 * (size_t)PIPE_C * (2 * TILE_N + 64))
+    lds_bytes = bf3 ? 3 * ((size_t)pv.MB * 2048 + 2 * ((size_t)(TILE_N / 32 + 1) * 1024 + 128))
                     : 2 * ((size_t)(PIPE_C / 2) * pv.MB * 64 + (size_t)PIPE_C * TILE_N) * sizeof(float);
     p.epi_lds_off = 0;                                       // the staging buffers are dead after the last barrier
     if (lds_bytes < epi_bytes) lds_bytes = epi_bytes;
@@ -1345,8 +1369,10 @@ __global__ __launch_bounds__(256) void pack_bf3_kernel(PackParams p, const int32
   const int32_t* e = pv.mg + 4 * gq;
   const int32_t* c = pv.chunk + 4 * q;
   const int lo = e[0], hi = e[1];
-  if (hi <= lo) return;
   const int MB = pv.MB, s = c[0];
+  if (blockIdx.y == 0 && threadIdx.x < 4)            // the 16-byte zero block behind the image (masked LDS-DMA pieces read it)
+    p.a[(long long)pv.n_stages * MB * 512 + threadIdx.x] = 0.f;
+  if (hi <= lo) return;
   const int total = (hi - lo) * MB * 64;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int lane = idx & 63;

@@ -68,7 +68,7 @@ class Plan:
     @property
     def packed_floats_bf3(self) -> int:
         """Size (in 4-byte words) of the split-bf16 image: per stage and 32-row block 64 lanes x (8 hi + 8 lo) bf16."""
-        return self.n_stages * self.MB * 512
+        return self.n_stages * self.MB * 512 + 4           # + a 16-byte zero block (source of masked LDS-DMA pieces)
 
     @property
     def length(self) -> int:

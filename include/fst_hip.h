@@ -65,7 +65,7 @@ int fst_pack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan
                      float* a_packed, void* stream);
 
 /* Same as fst_pack_weights, into the split-bf16 image the FST_GEMM_BF16X3 path of fst_conv_gemm reads
- * (plan.n_stages * MB * 2048 bytes): every weight w is stored as two round-to-nearest bf16 parts,
+ * (plan.n_stages * MB * 2048 bytes + a 16-byte zero block): every weight w is stored as two round-to-nearest bf16 parts,
  * hi = bf16(w) and lo = bf16(w - hi); stage s (= one live (M-group, chunk, tap) triple, 16 channels deep),
  * 32-row block mb: 64 lanes x 8 hi parts, then 64 lanes x 8 lo parts, lane l = row l&31, channels 8*(l>>5)+0..7
  * — the A-operand fragments of v_mfma_f32_32x32x16_bf16.  Only for plans made of single-tap stages of at

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostics: where a wave of conv_gemm_pipe_kernel spends its cycles (needs the FST_STAMPS build)."""
+"""Diagnostics: where a wave of conv_gemm_bf3_kernel spends its cycles (needs the FST_STAMPS build:
+tools/build_stamps.sh, then FST_HIP_LIB=build/exp/libfst_hip_stamps.so python tools/stage_timeline.py)."""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +10,7 @@ lib = _lib.load()
 lib.fst_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 dev = torch.device("cuda:0")
 B, L, n, h = 256, 512, 120, 25
-names = ["prologue", "fetch issue", "k-steps", "vmcnt wait", "commit", "barrier", "epilogue", "whole wave"]
+names = ["prologue", "next+vmcnt", "barrier", "dma issue", "B frags", "A+mfma", "epilogue", "whole wave"]
 
 
 def report(title, waves, stages):
