@@ -948,12 +948,20 @@ struct WgradParams {
 // channels (window = TW columns, up to WG_ITEMS windows per workgroup); WIDE=true: one windowed chunk of
 // ≤ 64 channels and ≤ 128 columns (omni-scale layers, all items of a workgroup share it).
 // The next (b,t) tile is fetched global→registers while the current one is multiplied.
-template <int CB, int TW, bool WIDE, bool VEC>
+//
+// BF3: the products run on the bf16 matrix cores with split operands (see conv_gemm_bf3_kernel): time is cut into
+// 16-deep k-steps; wave w owns item w (its 32 packed K-rows are the MFMA rows) against ALL 4·CB output-channel
+// blocks, so the A fragment — 8 consecutive raw fp32 samples of the staged x window at any tap offset, eight
+// ds_read_b32 — is split into hi / lo once, by the only wave that uses it; dy is split when it is staged, into two
+// bf16 images [M rows][32 samples] (80-byte rows: a 16-lane group's ds_read_b128 covers all 64 banks) shared by the
+// four waves.
+template <int CB, int TW, bool WIDE, bool VEC, bool BF3>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const int32_t* __restrict__ plan) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(TW == 32, "staging maps one half-wave to one 32-sample row");
   constexpr int MBW = 4 * CB;
   constexpr int DYS = TW + 1;   // odd row stride: lanes ↔ rows never share a bank
+  constexpr int DYB = 2 * TW + 16;                       // BF3: bytes per row of a dy image
   constexpr int DYV = MBW * 32 / 8;                      // dy floats per thread per tile
   constexpr int NREG = WIDE ? 1 : WG_ITEMS;              // staged windows per workgroup
   constexpr int XV = WIDE ? 32 : 4;                      // x floats per thread per window
@@ -964,7 +972,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
 
   float* xreg = lds;                                     // n_regions windows of region_floats
   float* zrow = lds + p.n_regions * p.region_floats;     // TW+2 zeros
-  float* dyt = zrow + (TW + 2 + 3) / 4 * 4;              // [MBW*32][DYS]
+  float* dyt = zrow + (TW + 2 + 3) / 4 * 4;              // [MBW*32][DYS]   (BF3: hi image, then lo image, [MBW*32][DYB bytes])
+  char* const dyh = reinterpret_cast<char*>(dyt);
+  char* const dyl = dyh + MBW * 32 * DYB;
 
   // decode this workgroup's items (all share one M-group)
   int it_q[WG_ITEMS], it_rb[WG_ITEMS], it_region[WG_ITEMS];
@@ -1126,10 +1136,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
   };
   auto commit = [&]() {
     if (VEC) {
+      if (BF3) {
+#pragma unroll
+        for (int i = 0; i < DYV / 4; ++i) {
+          unsigned h0, h1, l0, l1;
+          split_bf16_pair(dy_st[4 * i], dy_st[4 * i + 1], h0, l0);
+          split_bf16_pair(dy_st[4 * i + 2], dy_st[4 * i + 3], h1, l1);
+          const int off = (vrow + 32 * i) * DYB + vcol * 2;
+          *reinterpret_cast<uint2*>(dyh + off) = make_uint2(h0, h1);
+          *reinterpret_cast<uint2*>(dyl + off) = make_uint2(l0, l1);
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < DYV / 4; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) dyt[(vrow + 32 * i) * DYS + vcol + k] = dy_st[4 * i + k];
+      }
 #pragma unroll
       for (int r = 0; r < NREG; ++r) {
         if (reg_src[r] == nullptr) continue;
@@ -1151,8 +1173,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
       }
       return;
     }
+    if (BF3) {
+#pragma unroll
+      for (int i = 0; i < DYV; ++i) {
+        unsigned hh, ll;
+        split_bf16_pair(dy_st[i], 0.f, hh, ll);
+        const int off = (wave * 2 + half + 8 * i) * DYB + l31 * 2;
+        *reinterpret_cast<unsigned short*>(dyh + off) = (unsigned short)hh;
+        *reinterpret_cast<unsigned short*>(dyl + off) = (unsigned short)ll;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < DYV; ++i) dyt[(wave * 2 + half + 8 * i) * DYS + l31] = dy_st[i];
+    }
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       if (reg_src[r] == nullptr) continue;
@@ -1182,6 +1215,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
     __syncthreads();
     if (tile + 1 < tile_end) fetch(tile + 1);
 
+    if (BF3) {
+      // wave w multiplies item w: rows = its 32 packed K-rows (lane's row: rowoff_w), columns = every output block
+      int roff = rowoff[0];
+#pragma unroll
+      for (int i = 1; i < WG_ITEMS; ++i) roff = wave == i ? rowoff[i] : roff;
+#pragma unroll
+      for (int ks = 0; ks < TW / 16; ++ks) {
+        const float* ap = lds + roff + ks * 16 + 8 * half;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ap[j];
+        u32x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned hh, ll;
+          split_bf16_pair(v[2 * j], v[2 * j + 1], hh, ll);
+          h[j] = hh; l[j] = ll;
+        }
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, h), al = __builtin_bit_cast(bf16x8, l);
+        const int boff = l31 * DYB + (ks * 16 + 8 * half) * 2;
+#pragma unroll
+        for (int i = 0; i < WG_ITEMS; ++i)
+#pragma unroll
+          for (int cb = 0; cb < CB; ++cb) {
+            const int blk = i * CB + cb;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(dyh + blk * 32 * DYB + boff);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(dyl + blk * 32 * DYB + boff);
+            acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][cb], 0, 0, 0);
+            acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][cb], 0, 0, 0);
+            acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][cb], 0, 0, 0);
+          }
+      }
+      continue;
+    }
     const float* bbase = dyt + (wave * CB * 32 + l31) * DYS + half;
     // straight-line k-steps: padding items multiply the zero row instead of branching around their MFMAs (all
     // workgroups of a launch are co-resident, so the launch lasts as long as a full workgroup either way)
@@ -1200,6 +1267,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
     }
   }
 
+  if (BF3) {
+    // this wave's item: acc[i][cb] is output-channel block i*CB+cb of item `wave`
+    int my_q = it_q[0], my_rb = it_rb[0];
+#pragma unroll
+    for (int i = 1; i < WG_ITEMS; ++i) { my_q = wave == i ? it_q[i] : my_q; my_rb = wave == i ? it_rb[i] : my_rb; }
+    if (wave >= nit || my_q < 0) return;
+    const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + my_q);
+    const int c_pad = (pv.chunk[4 * my_q + 2] + 1) & ~1;
+    const int nrows = (e[1] - e[0]) * c_pad;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = my_rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row >= nrows) continue;
+      const int tapi = row / c_pad, c = row - tapi * c_pad;
+      const long long rec = (long long)e[2] + tapi * (c_pad / 2) + (c >> 1);
+#pragma unroll
+      for (int i = 0; i < WG_ITEMS; ++i)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+          atomicAdd(p.da + (rec * MBW + i * CB + cb) * 64 + (c & 1) * 32 + l31, acc[i][cb][r]);
+    }
+    return;
+  }
   // epilogue: acc rows = packed K-rows (tap, channel), cols = output channel m (lane) → record layout
 #pragma unroll
   for (int i = 0; i < WG_ITEMS; ++i) {
@@ -1227,7 +1317,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
 extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs, const float* dy,
                               int64_t dy_bs, const float* dy2, int64_t dy2_bs, int msplit, float* da_packed,
                               const int32_t* plan_dev, const int32_t* plan_host, int plan_len, int B, int L, int M,
-                              int ksplit, void* stream) {
+                              int ksplit, int flags, void* stream) {
   if (int rc = fst_check_plan(plan_host, plan_len, M, "fst_conv_wgrad")) return rc;
   const PlanView pv = plan_view(plan_host);
   FST_REQUIRE(x0 && dy && da_packed && plan_dev, "fst_conv_wgrad: null operand");
@@ -1284,8 +1374,9 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   } else {
     FST_REQUIRE(pv.chunk_cap <= 32, "fst_conv_wgrad: single-tap plan needs chunks of <= 32 channels (got %d)", pv.chunk_cap);
   }
-  const size_t lds_floats = (size_t)p.n_regions * p.region_floats + (TW + 2 + 3) / 4 * 4 + (size_t)pv.MB * 32 * (TW + 1);
-  const size_t lds_bytes = lds_floats * sizeof(float);
+  const bool bf3 = (flags & FST_GEMM_BF16X3) != 0;
+  const size_t dy_bytes = bf3 ? 2 * (size_t)pv.MB * 32 * (2 * TW + 16) : (size_t)pv.MB * 32 * (TW + 1) * sizeof(float);
+  const size_t lds_bytes = ((size_t)p.n_regions * p.region_floats + (TW + 2 + 3) / 4 * 4) * sizeof(float) + dy_bytes;
   FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_conv_wgrad: LDS %zu B exceeds 160 KiB", lds_bytes);
   // 16-byte loads for narrow windows when every tile row address is 16-B aligned
   auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1301,12 +1392,20 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   const bool vec = L % 4 == 0 && (wide ? starts4 : shifts4) && x0_bs % 4 == 0 && x1_bs % 4 == 0 && dy_bs % 4 == 0 &&
                    dy2_bs % 4 == 0 && al16(x0) && al16(x1) && al16(dy) && al16(dy2);
   void (*fn)(WgradParams, const int32_t*);
-  if (pv.MB == 8) {
-    fn = wide ? (vec ? conv_wgrad_kernel<2, TW, true, true> : conv_wgrad_kernel<2, TW, true, false>)
-              : (vec ? conv_wgrad_kernel<2, TW, false, true> : conv_wgrad_kernel<2, TW, false, false>);
+  if (bf3) {
+    if (pv.MB == 8) {
+      fn = wide ? (vec ? conv_wgrad_kernel<2, TW, true, true, true> : conv_wgrad_kernel<2, TW, true, false, true>)
+                : (vec ? conv_wgrad_kernel<2, TW, false, true, true> : conv_wgrad_kernel<2, TW, false, false, true>);
+    } else {
+      fn = wide ? (vec ? conv_wgrad_kernel<1, TW, true, true, true> : conv_wgrad_kernel<1, TW, true, false, true>)
+                : (vec ? conv_wgrad_kernel<1, TW, false, true, true> : conv_wgrad_kernel<1, TW, false, false, true>);
+    }
+  } else if (pv.MB == 8) {
+    fn = wide ? (vec ? conv_wgrad_kernel<2, TW, true, true, false> : conv_wgrad_kernel<2, TW, true, false, false>)
+              : (vec ? conv_wgrad_kernel<2, TW, false, true, false> : conv_wgrad_kernel<2, TW, false, false, false>);
   } else {
-    fn = wide ? (vec ? conv_wgrad_kernel<1, TW, true, true> : conv_wgrad_kernel<1, TW, true, false>)
-              : (vec ? conv_wgrad_kernel<1, TW, false, true> : conv_wgrad_kernel<1, TW, false, false>);
+    fn = wide ? (vec ? conv_wgrad_kernel<1, TW, true, true, false> : conv_wgrad_kernel<1, TW, true, false, false>)
+              : (vec ? conv_wgrad_kernel<1, TW, false, true, false> : conv_wgrad_kernel<1, TW, false, false, false>);
   }
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)fn, "fst_conv_wgrad")) return rc;

@@ -220,9 +220,10 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
     dy_bs, _ = _ncl(dy, "dy")
     dy2_bs = _ncl(dy2, "dy2")[0] if dy2 is not None else 0
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    bf3 = MATH == "bf16x3"
     check(lib.fst_conv_wgrad(ptr(x0), x0_bs, ptr(x1), x1_bs, ptr(dy), dy_bs, ptr(dy2), dy2_bs, msplit, ptr(da),
-                             ptr(plan.dev(x0.device)), plan.host_ptr(), plan.length, B, L, M, ksplit, stream_ptr()),
-          "fst_conv_wgrad")
+                             ptr(plan.dev(x0.device)), plan.host_ptr(), plan.length, B, L, M, ksplit,
+                             GEMM_BF16X3 if bf3 else 0, stream_ptr()), "fst_conv_wgrad")
     if t0 is not None:
         wide = bool(((plan.entries()[:, :, 1] - plan.entries()[:, :, 0]) > 1).any())
         if wide:
@@ -234,7 +235,8 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
                                                   for t in (x0, x1, dy, dy2))
         else:
             vec = _vec16(plan, L, x0, x1, dy, dy2)
-        key = f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}, {'true' if vec else 'false'}>"
+        key = (f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}, {'true' if vec else 'false'}, "
+               f"{'true' if bf3 else 'false'}>")
         if KERNEL_TIMER.detail:
             key += f" M={M} rec={plan.total_records} ksplit={ksplit}"
         KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M))

@@ -111,11 +111,13 @@ int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs
 /* dA_packed[(g,q) records] += Σ_{b,t} dy[b,m,t]·xcol[b,k,t]  — weight-gradient engine (f32 MFMA,
  * split over (b,t) with fp32 atomics; the caller zero-fills da_packed).  Replaces the weight
  * gradient autograd derives for every conv listed above (Q1: with a dense plan it also yields the
- * masked-tap gradients the reference's GradNorm consumes, train_and_test.py:685-690). */
+ * masked-tap gradients the reference's GradNorm consumes, train_and_test.py:685-690).
+ * FST_GEMM_BF16X3: products on v_mfma_f32_32x32x16_bf16 with both operands split into two bf16 parts
+ * (hi*hi + hi*lo + lo*hi, fp32 accumulate), same layout of da_packed. */
 int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs,
                    const float* dy, int64_t dy_bs, const float* dy2, int64_t dy2_bs, int msplit,
                    float* da_packed, const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
-                   int B, int L, int M, int ksplit, void* stream);
+                   int B, int L, int M, int ksplit, int flags /* 0 or FST_GEMM_BF16X3 */, void* stream);
 
 /* out[m] (+)= Σ_{b,t} x[b,m,t]   (bias gradients; BN β gradient). */
 int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, void* stream);
