@@ -33,25 +33,25 @@ class KernelTimer:
 
     def __init__(self, detail: bool = False):
         self.detail = detail       # True: key launches by shape as well (diagnostics)
-        self.records = {}          # key -> list of (start_event, end_event, algorithmic_flops)
+        self.records = {}          # key -> list of (start_event, end_event, algorithmic_flops, algorithmic_hbm_bytes)
 
     def begin(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
 
-    def end(self, key: str, start, flops: float):
+    def end(self, key: str, start, flops: float, nbytes: float = 0.0):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-        self.records.setdefault(key, []).append((start, ev, flops))
+        self.records.setdefault(key, []).append((start, ev, flops, nbytes))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for key, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             out[key] = {"launches": len(recs), "total_ms": ms, "avg_us": 1e3 * ms / len(recs),
-                        "flops": sum(f for _, _, f in recs)}
+                        "flops": sum(r[2] for r in recs), "bytes": sum(r[3] for r in recs)}
         return out
 
 
@@ -208,7 +208,14 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
             key = f"conv_gemm_kernel<{plan.MB}, {nb}>"
         if KERNEL_TIMER.detail:
             key += f" M={M} rec={plan.total_records} dil={plan.dil}"
-        KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
+        # algorithmic HBM bytes: every operand tensor once (inputs, residual / accumulate operands, outputs)
+        rows_in = x0.size(1) + (x1.size(1) if x1 is not None else 0) + (res.size(1) if res is not None else 0)
+        rows_out = (msplit if y is not None else 0) + ((M - m2_start) if y2 is not None else 0)
+        if y2 is not None and flags & EPI_ACC2:
+            rows_in += M - m2_start
+        if flags & EPI_ACC1 and y is not None:
+            rows_in += msplit
+        KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M), 4.0 * B * L * (rows_in + rows_out))
 
 
 def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor], msplit: int, B: int,
@@ -239,7 +246,8 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
                f"{'true' if bf3 else 'false'}>")
         if KERNEL_TIMER.detail:
             key += f" M={M} rec={plan.total_records} ksplit={ksplit}"
-        KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M))
+        rows_in = x0.size(1) + (x1.size(1) if x1 is not None else 0) + M
+        KERNEL_TIMER.end(key, t0, 2.0 * B * L * _plan_macs_per_step(plan, M), 4.0 * B * L * rows_in + 8.0 * plan.packed_floats)
     return da
 
 

@@ -1,8 +1,10 @@
 """HIP kernels vs plain torch references (fp64 on the CPU), through the C ABI.  Needs an MI355X.
 
 Tolerances: the f32 MFMA is an exact fp32 FMA chain, so conv results match an fp64 reference to
-~1e-6 relative to the operand scale; we assert 2e-5·scale (forward/data-grad) and 1e-4·scale for
-weight gradients (fp32 atomics across (b,t) splits, sums of B·L terms).
+~1e-6 relative to the operand scale; the split-bf16 path (three bf16 MFMAs per product, fp32
+accumulate — the default for 16-byte-alignable shapes) measures ~5e-6.  We assert 2e-5·scale
+(forward/data-grad) and 1e-4·scale for weight gradients (fp32 atomics across (b,t) splits, sums of
+B·L terms) in BOTH arithmetic modes (``ops.MATH`` = "bf16x3" | "f32").
 """
 import numpy as np
 import pytest
@@ -43,8 +45,16 @@ CASES = [  # M, C0, ntaps, dil, pad_left, C1, B, L
 ]
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def arithmetic(request):
+    """Run a test once per GEMM arithmetic (ops.MATH), restoring the default afterwards."""
+    prev, ops.MATH = ops.MATH, request.param
+    yield request.param
+    ops.MATH = prev
+
+
 @pytest.mark.parametrize("M,C0,ntaps,dil,pad_left,C1,B,L", CASES)
-def test_conv_forward_backward(M, C0, ntaps, dil, pad_left, C1, B, L):
+def test_conv_forward_backward(M, C0, ntaps, dil, pad_left, C1, B, L, arithmetic):
     g = torch.Generator().manual_seed(M + 7 * C0 + L)
     spec = ops.ConvSpec(M, C0, ntaps, dil, pad_left, C1=C1)
     x0 = torch.randn(B, C0, L, generator=g, dtype=torch.float64, requires_grad=True)
@@ -103,7 +113,7 @@ def test_conv_epilogues_split_residual_accumulate():
 
 
 @pytest.mark.parametrize("which", ["L0", "L1", "L2", "CLF0", "small"])
-def test_omni_scale_layers(which):
+def test_omni_scale_layers(which, arithmetic):
     """The metric config's omni-scale layers (L=512, C_in=1): masked-tap skipping forward / data-grad, and
     DENSE weight gradients (quirk Q1)."""
     if which == "small":
@@ -250,7 +260,7 @@ def test_cpc_nce(B, C, L, T, t0):
     assert_close(fd.grad, feat.grad, 5e-5, "dfeat"); assert_close(pd.grad, pred.grad, 5e-5, "dpred")
 
 
-def test_fixed_matmul():
+def test_fixed_matmul(arithmetic):
     g = torch.Generator().manual_seed(9)
     Bx, D, O = 7, 640, 64
     x = torch.randn(Bx, D, generator=g, dtype=torch.float64, requires_grad=True)
