@@ -736,6 +736,178 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_bf3_kernel(ConvGemmParams p,
   FST_FLUSH;
 }
 
+// ------------------------------------------------------------------------------------------------
+// omni-scale layers on the bf16 matrix cores (split operands, see conv_gemm_bf3_kernel).
+//
+// The window idea of conv_gemm_kernel with 16-channel chunks: a chunk's input window is staged ONCE per
+// workgroup, already split, as two bf16 images laid out [time][16 channels] (32-byte rows).  A tap is then a ROW
+// offset: the MFMA B fragment of (tap, 32 time samples) — 8 channels of one sample per lane — is one 16-byte
+// aligned ds_read_b128 per image whatever the tap (a wave's 64 lanes read 2 KiB contiguous), with no VALU work
+// in the tap loop.  A fragments (the hi/lo weight image of fst_pack_weights_bf16x3, one 16-deep stage per
+// (M-group, chunk, tap)) stream from L2 through a register ring.  Per 32-row block only the block's live taps are
+// multiplied; all M-groups of a workgroup share the staged windows when every chunk fits in LDS at once.
+// ------------------------------------------------------------------------------------------------
+template <int MB, int NB>
+__global__ __launch_bounds__(256, 2) void conv_win_bf3_kernel(ConvGemmParams p, const int32_t* __restrict__ plan) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int TILE_N = 128 * NB;
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const PlanView pv = plan_view(plan);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.tiles_per_seq;
+  const int t0 = (blockIdx.x - b * p.tiles_per_seq) * TILE_N;
+  const int g_begin = blockIdx.y * p.mg_per_wg;
+  const int g_end = min(pv.n_mgroups, g_begin + p.mg_per_wg);
+  const int q_begin = (int)(((long long)blockIdx.z * pv.n_chunks) / p.ksplit);
+  const int q_end = (int)(((long long)(blockIdx.z + 1) * pv.n_chunks) / p.ksplit);
+  const int wave_n0 = wave * NB * 32;
+  const int L = p.L, dil = pv.dil;
+  const int slot_bytes = p.ldw * 64;                    // one chunk: hi image [ldw rows][32 B], then lo image
+
+  auto window = [&](int q, int g0, int g1, int& jlo, int& width) {
+    int lo = 1 << 30, hi = -1;
+    for (int g = g0; g < g1; ++g) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      if (e[1] > e[0]) { lo = min(lo, e[0]); hi = max(hi, e[1]); }
+    }
+    if (hi < 0) { jlo = 0; width = 0; return; }
+    jlo = lo * dil;
+    width = (hi - 1 - lo) * dil + TILE_N;
+  };
+  // stage chunk q: thread = (time j, channel quad cq): 4 channels of one sample -> 8 bytes of each image row
+  auto stage = [&](int q, int slot, int jlo, int width) {
+    const int32_t* c = pv.chunk + 4 * q;
+    const int src = c[0], c_begin = c[1], c_count = c[2];
+    const float* xb = p.x[src] + (long long)b * p.x_bs[src] + (long long)c_begin * L;
+    const int tbase = t0 - pv.pad_left + jlo;
+    char* const hi_img = ldsb + slot * slot_bytes;
+    char* const lo_img = hi_img + p.ldw * 32;
+    const int cq = tid & 3;
+    for (int j = tid >> 2; j < width; j += 64) {
+      const int t = tbase + j;
+      const bool t_ok = t >= 0 && t < L;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int cc = 4 * cq + k;
+        v[k] = (t_ok && cc < c_count) ? xb[(long long)cc * L + t] : 0.f;
+      }
+      unsigned h0, h1, l0, l1;
+      split_bf16_pair(v[0], v[1], h0, l0);
+      split_bf16_pair(v[2], v[3], h1, l1);
+      *reinterpret_cast<uint2*>(hi_img + j * 32 + cq * 8) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(lo_img + j * 32 + cq * 8) = make_uint2(l0, l1);
+    }
+  };
+
+  // every chunk of this K range resident at once (host-decided): stage them all, then every M-group reuses them
+  const bool resident = p.stage_vec != 0;               // (field reused: 1 = all chunks fit)
+  int jlo_all = 0, width_all = 0;
+  if (resident) {
+    for (int q = q_begin; q < q_end; ++q) {
+      int jl, w;
+      window(q, g_begin, g_end, jl, w);
+      // one common origin for all chunks: the union window
+      if (q == q_begin) { jlo_all = jl; width_all = w; }
+      else if (w > 0) {
+        const int lo2 = min(jlo_all, jl), hi2 = max(jlo_all + width_all, jl + w);
+        if (width_all == 0) { jlo_all = jl; width_all = w; } else { jlo_all = lo2; width_all = hi2 - lo2; }
+      }
+    }
+    for (int q = q_begin; q < q_end; ++q) stage(q, q - q_begin, jlo_all, width_all);
+    __syncthreads();
+  }
+
+  for (int g = g_begin; g < g_end; ++g) {
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    for (int q = q_begin; q < q_end; ++q) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      const int lo = e[0], hi = e[1];
+      int jlo = jlo_all, slot = q - q_begin;
+      if (!resident) {
+        int width;
+        window(q, g, g + 1, jlo, width);
+        slot = 0;
+        __syncthreads();   // previous chunk's readers are done
+        stage(q, 0, jlo, width);
+        __syncthreads();
+      }
+      if (hi <= lo) continue;
+      const int nk = hi - lo;                                // one 16-deep k-step per live tap
+      const uint4* ap = reinterpret_cast<const uint4*>(p.a) + (long long)e[3] * (MB * 128) + lane;
+      constexpr int RING = MB == 1 ? 4 : 2;
+      uint4 rh[RING][MB], rl[RING][MB];
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        const int kk = j < nk ? j : nk - 1;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          rh[j][mb] = ap[(kk * MB + mb) * 128];
+          rl[j][mb] = ap[(kk * MB + mb) * 128 + 64];
+        }
+      }
+      const char* hi_img = ldsb + slot * slot_bytes + (wave_n0 + l31 - jlo) * 32 + half * 16;
+      const char* lo_img = hi_img + p.ldw * 32;
+      int tap = lo;
+      auto kstep = [&](const uint4 (&ah)[MB], const uint4 (&al)[MB]) {
+        const int roff = tap * dil * 32;
+        bf16x8 bh[NB], bl[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          bh[nb] = *reinterpret_cast<const bf16x8*>(hi_img + roff + nb * 1024);
+          bl[nb] = *reinterpret_cast<const bf16x8*>(lo_img + roff + nb * 1024);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah[mb]), a_l = __builtin_bit_cast(bf16x8, al[mb]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh[nb], acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl[nb], acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh[nb], acc[mb][nb], 0, 0, 0);
+          }
+        }
+        ++tap;
+      };
+      int kb = 0;
+      for (; kb + RING <= nk; kb += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+          uint4 ah[MB], al[MB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) { ah[mb] = rh[j][mb]; al[mb] = rl[j][mb]; }
+          const int kn = kb + j + RING < nk ? kb + j + RING : nk - 1;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            rh[j][mb] = ap[(kn * MB + mb) * 128];
+            rl[j][mb] = ap[(kn * MB + mb) * 128 + 64];
+          }
+          kstep(ah, al);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        if (kb + j < nk) {
+          uint4 ah[MB], al[MB];
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) { ah[mb] = rh[j][mb]; al[mb] = rl[j][mb]; }
+          kstep(ah, al);
+        }
+      }
+    }
+
+    conv_epilogue<MB, NB>(p, acc, g, b, t0, wave_n0, half, l31, p.bias != nullptr && blockIdx.z == 0, lds);
+  }
+}
+
 static bool plan_is_pipeable(const PlanView& pv) {
   for (int q = 0; q < pv.n_chunks; ++q) {
     if (((pv.chunk[4 * q + 2] + 1) & ~1) > PIPE_C) return false;
@@ -792,6 +964,28 @@ static conv_gemm_fn pick_conv_gemm_pipe_v(int MB, int NB) {
 }
 static conv_gemm_fn pick_conv_gemm_pipe(int MB, int NB, bool vec = false) {
   return vec ? pick_conv_gemm_pipe_v<true>(MB, NB) : pick_conv_gemm_pipe_v<false>(MB, NB);
+}
+
+static conv_gemm_fn pick_conv_win_bf3(int MB, int NB) {
+  if (NB == 1) {
+    switch (MB) {
+      case 1: return conv_win_bf3_kernel<1, 1>;
+      case 2: return conv_win_bf3_kernel<2, 1>;
+      case 4: return conv_win_bf3_kernel<4, 1>;
+    }
+  } else if (NB == 2) {
+    switch (MB) {
+      case 1: return conv_win_bf3_kernel<1, 2>;
+      case 2: return conv_win_bf3_kernel<2, 2>;
+      case 4: return conv_win_bf3_kernel<4, 2>;
+    }
+  } else if (NB == 4) {
+    switch (MB) {
+      case 1: return conv_win_bf3_kernel<1, 4>;
+      case 2: return conv_win_bf3_kernel<2, 4>;
+    }
+  }
+  return nullptr;
 }
 
 static conv_gemm_fn pick_conv_gemm_bf3(int MB, int NB) {
@@ -862,13 +1056,18 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   const bool vec = pipe && L % 4 == 0 && shifts4 && x0_bs % 4 == 0 && al16(x0) &&
                    (x1 == nullptr || (x1_bs % 4 == 0 && al16(x1)));
   const bool bf3 = (flags & FST_GEMM_BF16X3) != 0;
-  if (bf3) {
-    FST_REQUIRE(pipe, "fst_conv_gemm: FST_GEMM_BF16X3 needs a pipelined plan (single-tap stages of <= 16 channels) and NB <= 2");
+  const bool win3 = bf3 && !pipe;                        // windowed plan of <= 16-channel chunks: the bf16 window kernel
+  if (bf3 && pipe) {
     FST_REQUIRE(L % 4 == 0 && x0_bs % 4 == 0 && al16(x0) && (x1 == nullptr || (x1_bs % 4 == 0 && al16(x1))),
                 "fst_conv_gemm: FST_GEMM_BF16X3 needs L %% 4 == 0 and 16-byte aligned activations (L=%d)", L);
   }
-  conv_gemm_fn fn = bf3 ? pick_conv_gemm_bf3(pv.MB, nb_cfg)
-                        : (pipe ? pick_conv_gemm_pipe(pv.MB, nb_cfg, vec) : pick_conv_gemm(pv.MB, nb_cfg));
+  if (win3)
+    FST_REQUIRE(pv.chunk_cap <= 16 && pick_conv_win_bf3(pv.MB, nb_cfg) != nullptr,
+                "fst_conv_gemm: FST_GEMM_BF16X3 on a windowed plan needs chunks of <= 16 channels (got %d) and a supported "
+                "MB x NB (%d x %d)", pv.chunk_cap, pv.MB, nb_cfg);
+  conv_gemm_fn fn = win3 ? pick_conv_win_bf3(pv.MB, nb_cfg)
+                         : (bf3 ? pick_conv_gemm_bf3(pv.MB, nb_cfg)
+                                : (pipe ? pick_conv_gemm_pipe(pv.MB, nb_cfg, vec) : pick_conv_gemm(pv.MB, nb_cfg)));
   FST_REQUIRE(fn != nullptr, "fst_conv_gemm: no kernel for MB=%d NB=%d", pv.MB, nb_cfg);
   const int TILE_N = 128 * nb_cfg;
 
@@ -898,6 +1097,12 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
       }
     }
   }
+  int max_w_single = 0;
+  for (int q = 0; q < pv.n_chunks; ++q)
+    for (int g = 0; g < pv.n_mgroups; ++g) {
+      const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+      if (e[1] > e[0]) { int w = (e[1] - 1 - e[0]) * pv.dil + TILE_N; max_w_single = max_w_single > w ? max_w_single : w; }
+    }
   FST_REQUIRE(max_w > 0, "fst_conv_gemm: plan has no live taps");
   p.ldw = (max_w + 3) & ~3;                               // 16-B aligned LDS rows (float4 staging)
   size_t lds_bytes = (size_t)pv.chunk_cap * p.ldw * sizeof(float);
@@ -912,6 +1117,24 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
                     : 2 * ((size_t)(PIPE_C / 2) * pv.MB * 64 + (size_t)PIPE_C * TILE_N) * sizeof(float);
     p.epi_lds_off = 0;                                       // the staging buffers are dead after the last barrier
     if (lds_bytes < epi_bytes) lds_bytes = epi_bytes;
+  } else if (win3) {
+    // bf16 window images: per chunk [ldw rows][16 ch] hi + lo = ldw*64 bytes.  All chunks resident (every M-group of
+    // the workgroup reuses them) when they fit next to a second workgroup; otherwise one slot, one M-group per
+    // workgroup.  max_w above was computed for mg_per_wg == 1 or a single chunk; recompute for the union window.
+    int lo_all = 1 << 30, hi_all = -1;
+    for (int q = 0; q < pv.n_chunks; ++q)
+      for (int g = 0; g < pv.n_mgroups; ++g) {
+        const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
+        if (e[1] > e[0]) { lo_all = lo_all < e[0] ? lo_all : e[0]; hi_all = hi_all > e[1] ? hi_all : e[1]; }
+      }
+    const int w_union = (hi_all - 1 - lo_all) * pv.dil + TILE_N;
+    const bool resident = ksplit == 1 && (size_t)pv.n_chunks * w_union * 64 + epi_bytes <= 76 * 1024;
+    p.stage_vec = resident ? 1 : 0;
+    p.mg_per_wg = resident ? pv.n_mgroups : 1;
+    p.ldw = resident ? w_union : max_w_single;
+    lds_bytes = (size_t)(resident ? pv.n_chunks : 1) * p.ldw * 64;
+    p.epi_lds_off = (int)((lds_bytes / sizeof(float) + 3) / 4 * 4);
+    lds_bytes = (size_t)p.epi_lds_off * sizeof(float) + epi_bytes;       // the epilogue's transpose tiles (vec or not)
   } else {
     p.epi_lds_off = (int)((lds_bytes / sizeof(float) + 3) / 4 * 4);   // after the staged window (reused across M-groups)
     if (p.epi_vec) lds_bytes = (size_t)p.epi_lds_off * sizeof(float) + epi_bytes;
@@ -1519,7 +1742,8 @@ static int launch_pack(const int32_t* plan_dev, const int32_t* plan_host, int pl
   PackParams p = p0;
   p.plan = plan_dev;
   if (bf3) {
-    FST_REQUIRE(plan_is_pipeable(pv), "%s: the split-bf16 image needs single-tap stages of <= %d channels", who, PIPE_C);
+    FST_REQUIRE(pv.chunk_cap <= PIPE_C, "%s: the split-bf16 image needs chunks of <= %d channels (got %d)", who, PIPE_C,
+                pv.chunk_cap);
     hipLaunchKernelGGL(pack_bf3_kernel, dim3(1, (unsigned)(pv.n_chunks * (p0.g_end - p0.g_begin))), dim3(256), 0,
                        (hipStream_t)stream, p, plan_dev);
   } else {

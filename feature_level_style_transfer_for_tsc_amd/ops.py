@@ -71,7 +71,9 @@ def _vec16(plan: Plan, L: int, *tensors) -> bool:
 def bf3_ok(plan: Plan, L: int) -> bool:
     """Whether a conv_gemm launch of ``plan`` at sequence length L takes the split-bf16 path (activations of a
     multiple-of-4 length are 16-byte aligned by construction: channel stride L, batch stride C*L)."""
-    return MATH == "bf16x3" and plan.pipeable and L % 4 == 0
+    if MATH != "bf16x3":
+        return False
+    return (plan.pipeable and L % 4 == 0) or plan.windowed16
 
 
 def _plan_macs_per_step(plan: Plan, M: int) -> int:
@@ -201,7 +203,7 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
                             M, nb, ksplit, flags, stream_ptr()), "fst_conv_gemm")
     if t0 is not None:
         if bf3:
-            key = f"conv_gemm_bf3_kernel<{plan.MB}, {nb}>"
+            key = f"conv_gemm_bf3_kernel<{plan.MB}, {nb}>" if plan.pipeable else f"conv_win_bf3_kernel<{plan.MB}, {nb}>"
         elif plan.pipeable and nb <= 2:
             key = f"conv_gemm_pipe_kernel<{plan.MB}, {nb}, {'true' if _vec16(plan, L, x0, x1) else 'false'}>"
         else:
@@ -296,6 +298,8 @@ class ConvSpec:
         many taps; channels are chunked to fit the LDS budget by ``_chunking``); otherwise the pipelined kernel,
         which has NB ∈ {1, 2}."""
         tiles128 = (L + 127) // 128
+        if windowed_c >= 8 and MATH == "bf16x3":
+            windowed_c, mb = min(windowed_c, PIPE_C), min(mb, 2)               # bf16 window kernel: 16-channel slots, MB <= 2
         best = 1
         for nb in ((4, 2, 1) if windowed_c else (2, 1)):
             if mb * nb > 8 or nb > max(1, tiles128):
@@ -324,6 +328,8 @@ class ConvSpec:
         """(chunk_c, split_taps)"""
         if not self._windowed(channels):
             return PIPE_C, True
+        if MATH == "bf16x3" and channels >= 8:
+            return PIPE_C, False                                                # bf16 window kernel: 16-channel chunks, all taps
         halo = (ntaps - 1) * self.dil
         cap = (LDS_BUDGET // (4 * (128 * nb + halo))) & ~1
         if channels <= cap:
@@ -337,7 +343,8 @@ class ConvSpec:
         key = ("fwd", nb)
         if key not in self._plans:
             chunk_c, split = self._chunking(max(self.C0, self.C1), nb, self.ntaps)
-            self._plans[key] = build_plan(self.M, self._fwd_segments(), self.ntaps, self.dil, self.pad_left, MB=self.mb,
+            mb = min(self.mb, 2) if (chunk_c == PIPE_C and not split) else self.mb     # bf16 window kernel: MB <= 2
+            self._plans[key] = build_plan(self.M, self._fwd_segments(), self.ntaps, self.dil, self.pad_left, MB=mb,
                                           chunk_c=chunk_c, split_taps=split, row_live=self.row_live)
         return self._plans[key]
 
@@ -348,8 +355,9 @@ class ConvSpec:
             if self.row_live is not None:
                 col_live = [(self.ntaps - hi, self.ntaps - lo) for lo, hi in self.row_live]
             chunk_c, split = self._chunking(self.M, nb, self.ntaps)
+            mb = min(pick_mb(self.C0), 2) if (chunk_c == PIPE_C and not split) else None   # bf16 window kernel: MB <= 2
             self._plans[key] = build_plan(self.C0, [Segment(0, self.M, 0, self.ntaps, col_live)], self.ntaps, self.dil,
-                                          self._halo() - self.pad_left, chunk_c=chunk_c, split_taps=split)
+                                          self._halo() - self.pad_left, MB=mb, chunk_c=chunk_c, split_taps=split)
         return self._plans[key]
 
     def dx1_plan(self, nb: int) -> Plan:

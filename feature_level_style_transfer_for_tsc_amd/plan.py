@@ -84,6 +84,13 @@ class Plan:
         en = self.entries()
         return self.chunk_cap <= 16 and bool(((en[:, :, 1] - en[:, :, 0]) <= 1).all())
 
+    @property
+    def windowed16(self) -> bool:
+        """True for a windowed (multi-tap) plan cut into chunks of 8..16 channels: the split-bf16 window kernel's
+        shape (conv_win_bf3_kernel in csrc/conv_engine.hip)."""
+        en = self.entries()
+        return 8 <= self.chunk_cap <= 16 and bool(((en[:, :, 1] - en[:, :, 0]) > 1).any())
+
     def dev(self, device):
         """int32 copy of the table on ``device`` (cached)."""
         import torch

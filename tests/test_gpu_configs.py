@@ -27,7 +27,8 @@ def close_piecewise(got, want, tol, what):
     """Gradient of a ReLU network at a random point: a pre-activation within rounding distance of 0 may take the
     other branch on the GPU than on the CPU (about 0.4 expected flips per ReLU layer at 2x50x5000 elements and 1e-6
     relative rounding), which changes dx by O(scale) inside that element's receptive field only (<= 89+89+2 samples x 9
-    channels).  So: every element within tol except inside at most 4 receptive-field-sized windows (<= 3 % of the
+    channels); the split-bf16 arithmetic (5e-6 instead of 1e-6 of the output scale per GEMM) flips about five times
+    as many.  So: every element within tol except inside at most 16 receptive-field-sized windows (<= 8 % of the
     elements), and a small relative L2 error overall."""
     got, want = got.detach().double().cpu(), want.detach().double().cpu()
     s = max(1e-6, float(want.abs().max()))
@@ -43,7 +44,7 @@ def close_piecewise(got, want, tol, what):
             windows += 1 + int((t[1:] - t[:-1] > 200).sum())
     msg = f"{what}: max err {float(err.max()):.3e}, scale {s:.3e}, outliers {frac:.2e} in {windows} windows, rel L2 {l2:.2e}"
     print(msg)
-    assert frac <= 3e-2 and windows <= 4 and l2 <= 2e-3, msg
+    assert frac <= 8e-2 and windows <= 16 and l2 <= 6e-3, msg
 
 
 def test_config0_gunpoint_shaped_classifier_step():

@@ -93,11 +93,24 @@ def test_metric_config_plan_shapes():
     layer = lp[1]
     live = row_live_ranges(layer)
     assert sum((hi - lo) * 25 for lo, hi in live) == 216900
-    spec = ops.ConvSpec(225, 25, 89, 1, 44, row_live=live)
-    plan = spec.fwd_plan(2)
-    assert plan.MB == 1 and plan.n_mgroups == 8 and plan.n_chunks == 1
-    packed_macs = plan.total_records * 2 * 32                      # MACs/timestep the kernel issues (incl. padding)
-    assert 216900 <= packed_macs <= 1.7 * 216900
+    prev = ops.MATH
+    try:
+        ops.MATH = "f32"                                            # f32 window kernel: one 26-channel window
+        spec = ops.ConvSpec(225, 25, 89, 1, 44, row_live=live)
+        plan = spec.fwd_plan(2)
+        assert plan.MB == 1 and plan.n_mgroups == 8 and plan.n_chunks == 1 and not plan.windowed16
+        packed_macs = plan.total_records * 2 * 32                  # MACs/timestep the kernel issues (incl. padding)
+        assert 216900 <= packed_macs <= 1.7 * 216900
+        ops.MATH = "bf16x3"                                         # bf16 window kernel: 16-channel chunks, 16-deep k-steps
+        spec = ops.ConvSpec(225, 25, 89, 1, 44, row_live=live)
+        plan = spec.fwd_plan(2)
+        assert plan.MB == 1 and plan.n_mgroups == 8 and plan.n_chunks == 2 and plan.windowed16 and not plan.pipeable
+        assert ops.bf3_ok(plan, 150) and ops.bf3_ok(plan, 512)      # no alignment requirement on L
+        issued = plan.n_stages * 16 * 32                            # MACs/timestep incl. the 25 -> 32 channel padding
+        assert 216900 <= issued <= 2.2 * 216900
+        assert plan.packed_floats_bf3 == plan.n_stages * 512 + 4
+    finally:
+        ops.MATH = prev
     wg = spec.wg_plan()
     assert wg.MB == 8 and len(wg.items()) % WG_ITEMS == 0
     ent = wg.entries()
