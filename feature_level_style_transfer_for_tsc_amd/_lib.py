@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
@@ -46,7 +46,7 @@ _SIGNATURES = {
     "fst_bn_finalize": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_void_p]),
     "fst_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_void_p]),
     "fst_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_void_p]),
-    "fst_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fst_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fst_gate_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_void_p]),
     "fst_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_void_p]),
     "fst_coupling_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_void_p]),
@@ -55,8 +55,9 @@ _SIGNATURES = {
     "fst_coupling_inv_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_void_p]),
     "fst_axpy": (c_int, [_P, _P, c_float, c_int64, c_void_p]),
     "fst_add_slices": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_void_p]),
-    "fst_cpc_nce_fwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, c_int, c_int, c_int, _P, _P, c_void_p]),
-    "fst_cpc_nce_bwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_void_p]),
+    "fst_cpc_nce_fwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_void_p]),
+    "fst_cpc_nce_bwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
+                                c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import dist as _dist
 from . import ops
 
 
@@ -87,8 +88,24 @@ def CDAN(input_target, input_g_from_source, prob_target, prob_g_from_source, ad_
     entropy_g_from_source.register_hook(grl_hook(coeff))
     weight_target = 1.0 + torch.exp(-entropy_target)
     weight_g_from_source = 1.0 + torch.exp(-entropy_g_from_source)
+    if _dist.global_batch_active():
+        return _q4_sum_global(weight_target, target_out) - _q4_sum_global(weight_g_from_source, g_source_out)
     weight_target = weight_target / torch.sum(weight_target).detach()
     weight_g_from_source = weight_g_from_source / torch.sum(weight_g_from_source).detach()
     distance_target = torch.sum(weight_target * target_out)                 # [B]·[B,1] → [B,B] (Q4)
     distance_g_from_source = torch.sum(weight_g_from_source * g_source_out)
     return distance_target - distance_g_from_source
+
+
+def _q4_sum_global(w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """Q4 over the samples of every rank: the [B]·[B,1] broadcast sums to (Σ_b w_b / S)·(Σ_b out_b) with
+    S = Σ_b w_b detached — a product of two GLOBAL batch sums, W_g·O_g / S_g.  Each rank returns the global value and
+    carries the gradient of its own samples, scaled by the world size because the bucket later averages parameter
+    gradients while this term is a sum over the batch, not a mean:  ∂/∂w_b = O_g/S_g,  ∂/∂out_b = W_g/S_g = 1."""
+    n = _dist.world()
+    W_r, O_r = torch.sum(w), torch.sum(out)
+    tot = torch.stack([W_r.detach(), O_r.detach()])
+    _dist.sum_over_ranks_(tot)
+    W_g, O_g = tot[0], tot[1]
+    carrier = n * ((W_r / W_g) * O_g + O_r)
+    return carrier - carrier.detach() + O_g

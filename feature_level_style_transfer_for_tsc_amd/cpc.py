@@ -11,6 +11,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from . import dist as _dist
 from . import ops
 
 
@@ -46,4 +47,5 @@ class CPC(nn.Module):
         W = torch.stack([l.weight for l in self.Wk])                          # [T, C, H]
         b = torch.stack([l.bias for l in self.Wk])                            # [T, C]
         pred = torch.baddbmm(b.unsqueeze(1), c_t.unsqueeze(0).expand(T, B, -1), W.transpose(1, 2))   # [T, B, C]
-        return ops.CPCNceFn.apply(features, pred, t0, T)
+        # global-batch data parallelism: the negatives of a row are the predictions of EVERY rank's samples
+        return ops.CPCNceFn.apply(features, _dist.gather_cat(pred, 1), t0, T, _dist.rank() * B)

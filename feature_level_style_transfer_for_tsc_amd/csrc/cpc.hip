@@ -6,6 +6,10 @@
 //
 // enc is read in place from the feature tensor through (s_i, s_b, s_c) element strides, so no
 // [T,B,C] gather copy is made; denc is written through the same strides.
+//
+// Rows (enc samples, B) and columns (pred samples = negatives, Bc) may differ: in "global batch" data
+// parallelism a rank scores its B local rows against the Bc = world·B gathered predictions, its own
+// positives sitting at columns col_off + b (SURVEY §8e mode B).  Single GPU: Bc = B, col_off = 0.
 #include "fst_common.h"
 
 #define CPC_ROWS 16
@@ -32,17 +36,18 @@ struct CpcParams {
   float* dpred;        // [T][B][C]
   const int* t0_dev;   // optional device scalar: extra time offset of enc/denc (elements of stride s_i)
   int T, B, C;
+  int Bc, col_off;     // columns (pred rows) and the column of row 0's positive
 };
 
 __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.t0_dev) p.enc += (long long)p.t0_dev[0] * p.s_i;
   const int i = blockIdx.x, r0 = blockIdx.y * CPC_ROWS;
-  const int B = p.B, C = p.C, PS = C | 1;
-  float* predl = lds;                 // [B][PS]
-  float* encl = lds + (size_t)B * PS; // [CPC_ROWS][C]
-  const float* predg = p.pred + (long long)i * B * C;
-  for (int idx = threadIdx.x; idx < B * C; idx += 256) {
+  const int B = p.B, Bc = p.Bc, C = p.C, PS = C | 1;
+  float* predl = lds;                  // [Bc][PS]
+  float* encl = lds + (size_t)Bc * PS; // [CPC_ROWS][C]
+  const float* predg = p.pred + (long long)i * Bc * C;
+  for (int idx = threadIdx.x; idx < Bc * C; idx += 256) {
     const int j = idx / C, c = idx - j * C;
     predl[j * PS + c] = predg[idx];
   }
@@ -60,16 +65,16 @@ __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
     const float* er = encl + r * C;
     float mx = -INFINITY, diag = 0.f;
     // pass 1: max
-    for (int j = lane; j < B; j += 64) {
+    for (int j = lane; j < Bc; j += 64) {
       const float* pj = predl + j * PS;
       float d = 0.f;
       for (int c = 0; c < C; ++c) d = fmaf(er[c], pj[c], d);
       mx = fmaxf(mx, d);
-      if (j == b) diag = d;
+      if (j == b + p.col_off) diag = d;
     }
     mx = wave_max(mx);
     float se = 0.f;
-    for (int j = lane; j < B; j += 64) {
+    for (int j = lane; j < Bc; j += 64) {
       const float* pj = predl + j * PS;
       float d = 0.f;
       for (int c = 0; c < C; ++c) d = fmaf(er[c], pj[c], d);
@@ -94,18 +99,18 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
     p.denc += (long long)p.t0_dev[0] * p.s_i;
   }
   const int i = blockIdx.x;
-  const int B = p.B, C = p.C, PS = C | 1;
-  float* predl = lds;                              // [B][PS]
-  float* encl = predl + (size_t)B * PS;            // [CPC_ROWS][C]
-  float* dtl = encl + CPC_ROWS * C;                // [CPC_ROWS][B]
-  const float* predg = p.pred + (long long)i * B * C;
-  for (int idx = threadIdx.x; idx < B * C; idx += 256) {
+  const int B = p.B, Bc = p.Bc, C = p.C, PS = C | 1;
+  float* predl = lds;                              // [Bc][PS]
+  float* encl = predl + (size_t)Bc * PS;           // [CPC_ROWS][C]
+  float* dtl = encl + CPC_ROWS * C;                // [CPC_ROWS][Bc]
+  const float* predg = p.pred + (long long)i * Bc * C;
+  for (int idx = threadIdx.x; idx < Bc * C; idx += 256) {
     const int j = idx / C, c = idx - j * C;
     predl[j * PS + c] = predg[idx];
   }
   const float gs = p.gout[0] / ((float)B * (float)p.T);   // d nce / d total = (softmax − I)/(B·T)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int jcol = threadIdx.x;                           // this thread's dpred column (B ≤ 256)
+  const int jcol = threadIdx.x;                           // this thread's dpred column (Bc ≤ 256)
   float dp[CMAX];
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) dp[c] = 0.f;
@@ -122,15 +127,15 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
       const int b = r0 + r;
       const float* er = encl + r * C;
       const float lse = b < B ? p.lse[(long long)i * B + b] : 0.f;
-      for (int j = lane; j < B; j += 64) {
+      for (int j = lane; j < Bc; j += 64) {
         float v = 0.f;
         if (b < B) {
           const float* pj = predl + j * PS;
           float d = 0.f;
           for (int c = 0; c < C; ++c) d = fmaf(er[c], pj[c], d);
-          v = (expf(d - lse) - (j == b ? 1.f : 0.f)) * gs;
+          v = (expf(d - lse) - (j == b + p.col_off ? 1.f : 0.f)) * gs;
         }
-        dtl[r * B + j] = v;
+        dtl[r * Bc + j] = v;
       }
     }
     __syncthreads();
@@ -139,15 +144,15 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
       const int r = o / C, c = o - r * C;
       const int b = r0 + r;
       if (b >= B) continue;
-      const float* dr = dtl + r * B;
+      const float* dr = dtl + r * Bc;
       float s = 0.f;
-      for (int j = 0; j < B; ++j) s = fmaf(dr[j], predl[j * PS + c], s);
+      for (int j = 0; j < Bc; ++j) s = fmaf(dr[j], predl[j * PS + c], s);
       p.denc[i * p.s_i + b * p.s_b + c * p.s_c] = s;
     }
     // dpred[j][c] += Σ_b dt[b][j]·enc[b][c]
-    if (jcol < B) {
+    if (jcol < Bc) {
       for (int r = 0; r < CPC_ROWS; ++r) {
-        const float d = dtl[r * B + jcol];
+        const float d = dtl[r * Bc + jcol];
         const float* er = encl + r * C;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
@@ -155,8 +160,8 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
       }
     }
   }
-  if (jcol < B) {
-    float* out = p.dpred + ((long long)i * B + jcol) * C;
+  if (jcol < Bc) {
+    float* out = p.dpred + ((long long)i * Bc + jcol) * C;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
       if (c < C) out[c] = dp[c];
@@ -165,17 +170,20 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
 
 static int cpc_check(const CpcParams& p, size_t lds_bytes, const char* who) {
   FST_REQUIRE(p.enc && p.pred && p.lse && p.T > 0 && p.B > 0 && p.C > 0, "%s: bad arguments", who);
+  FST_REQUIRE(p.Bc >= p.B && p.col_off >= 0 && p.col_off + p.B <= p.Bc, "%s: %d rows at column offset %d do not fit %d columns",
+              who, p.B, p.col_off, p.Bc);
   FST_REQUIRE(lds_bytes <= 160 * 1024, "%s: pred tile %zu B exceeds LDS (B=%d C=%d)", who, lds_bytes, p.B, p.C);
   return 0;
 }
 
 extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev,
-                               const float* pred, int T, int B, int C, float* lse, float* nce_sum, void* stream) {
+                               const float* pred, int T, int B, int C, int Bc, int col_off, float* lse, float* nce_sum,
+                               void* stream) {
   CpcParams p = {};
   p.t0_dev = t0_dev;
   p.enc = enc; p.s_i = s_i; p.s_b = s_b; p.s_c = s_c; p.pred = pred; p.lse = lse; p.nce_sum = nce_sum;
-  p.T = T; p.B = B; p.C = C;
-  const size_t lds_bytes = ((size_t)B * (C | 1) + CPC_ROWS * C) * sizeof(float);
+  p.T = T; p.B = B; p.C = C; p.Bc = Bc; p.col_off = col_off;
+  const size_t lds_bytes = ((size_t)Bc * (C | 1) + CPC_ROWS * C) * sizeof(float);
   if (int rc = cpc_check(p, lds_bytes, "fst_cpc_nce_fwd")) return rc;
   FST_REQUIRE(nce_sum, "fst_cpc_nce_fwd: nce_sum is null");
   if (lds_bytes > 48 * 1024)
@@ -186,16 +194,16 @@ extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64
 }
 
 extern "C" int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev,
-                               const float* pred, const float* lse, int T, int B, int C, const float* gout, float* denc,
-                               float* dpred, void* stream) {
+                               const float* pred, const float* lse, int T, int B, int C, int Bc, int col_off,
+                               const float* gout, float* denc, float* dpred, void* stream) {
   CpcParams p = {};
   p.t0_dev = t0_dev;
   p.enc = enc; p.s_i = s_i; p.s_b = s_b; p.s_c = s_c; p.pred = pred; p.lse = const_cast<float*>(lse);
-  p.gout = gout; p.denc = denc; p.dpred = dpred; p.T = T; p.B = B; p.C = C;
-  const size_t lds_bytes = ((size_t)B * (C | 1) + CPC_ROWS * C + (size_t)CPC_ROWS * B) * sizeof(float);
+  p.gout = gout; p.denc = denc; p.dpred = dpred; p.T = T; p.B = B; p.C = C; p.Bc = Bc; p.col_off = col_off;
+  const size_t lds_bytes = ((size_t)Bc * (C | 1) + CPC_ROWS * C + (size_t)CPC_ROWS * Bc) * sizeof(float);
   if (int rc = cpc_check(p, lds_bytes, "fst_cpc_nce_bwd")) return rc;
   FST_REQUIRE(gout && denc && dpred, "fst_cpc_nce_bwd: null gradient buffer");
-  FST_REQUIRE(B <= 256, "fst_cpc_nce_bwd: B=%d > 256 negatives per rank not supported yet", B);
+  FST_REQUIRE(Bc <= 256, "fst_cpc_nce_bwd: %d > 256 negatives (columns) not supported yet", Bc);
   FST_REQUIRE(C <= 128, "fst_cpc_nce_bwd: C=%d > 128 not supported yet", C);
   void (*fn)(CpcParams) = C <= 32 ? cpc_bwd_kernel<32> : (C <= 64 ? cpc_bwd_kernel<64> : cpc_bwd_kernel<128>);
   if (lds_bytes > 48 * 1024)

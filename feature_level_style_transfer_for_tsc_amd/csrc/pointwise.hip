@@ -123,12 +123,13 @@ __global__ void bn_finalize_kernel(const float* sums, const float* gamma, const 
 }
 
 extern "C" int fst_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean,
-                               float* running_var, int train, int B, int C, int L, float eps, float momentum,
+                               float* running_var, int train, int B_total, int C, int L, float eps, float momentum,
                                float* stats, void* stream) {
   FST_REQUIRE(gamma && beta && running_mean && running_var && stats && C > 0, "fst_bn_finalize: bad arguments");
   FST_REQUIRE(!train || sums, "fst_bn_finalize: train mode needs sums");
+  FST_REQUIRE(!train || (B_total > 0 && L > 0), "fst_bn_finalize: B_total=%d L=%d", B_total, L);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta,
-                     running_mean, running_var, train, B * L, C, eps, momentum, stats);
+                     running_mean, running_var, train, B_total * L, C, eps, momentum, stats);
   FST_LAUNCH_CHECK();
   return 0;
 }
@@ -204,10 +205,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
 }
 
 extern "C" int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
-                                float* dx, int B, int C, int L, int relu, int train, void* stream) {
+                                float* dx, int B, int C, int L, int relu, int train, int B_total, void* stream) {
   FST_REQUIRE(dy && y && stats && dx && (!relu || out) && (!train || red), "fst_bn_bwd_apply: bad arguments");
+  FST_REQUIRE(B > 0 && C > 0 && L > 0 && B_total >= B, "fst_bn_bwd_apply: B=%d C=%d L=%d B_total=%d", B, C, L, B_total);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, y, out, stats, red, dx, C, L,
-                     relu, train, 1.0f / ((float)B * (float)L));
+                     relu, train, 1.0f / ((float)B_total * (float)L));
   FST_LAUNCH_CHECK();
   return 0;
 }

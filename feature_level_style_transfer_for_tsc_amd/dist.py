@@ -4,8 +4,20 @@ all-reduced over RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm; "gloo"
 The whole model is ≈ 8.9 M parameters ≈ 35.6 MB, so a single bucket (one collective per step) is the
 right shape for point-to-point xGMI links: per-link time ≈ 2·(N−1)/N·35.6 MB / 153 GB/s ≈ 0.4 ms.
 The step's only other collectives are two tiny scalar averages that keep GradNorm identical on every
-rank.  Batch-coupled statistics (BatchNorm batch moments, CPC negatives, NoiseTransfer means) stay
-per-rank — "DDP semantics" (SURVEY §8e mode A).
+rank.  Two modes:
+
+* **A, "DDP semantics"** (default; the benchmark): batch-coupled statistics (BatchNorm batch moments, CPC
+  negatives, NoiseTransfer means, CDAN's batch sums) stay per-rank; collectives = the bucket + 10 scalars,
+  outside the captured hipGraphs.
+* **B, "global-batch exact"** (``with global_batch(bucket):`` / ``JointTrainer(..., sync="global")``): every
+  batch-coupled quantity is formed over the samples of ALL ranks, so N ranks × B/N samples reproduce the
+  single-process step on the B-sample batch: SyncBN (moments and the two backward means all-reduced), CPC scored
+  against the predictions gathered from every rank, NoiseTransfer means and CDAN's batch sums all-reduced,
+  GradNorm's per-loss gradients averaged before their norms.  Eager only (collectives sit inside autograd).
+
+Gradient convention in both modes: every rank differentiates the mean over ITS samples; the bucket averages the
+parameter gradients.  A collective that mixes ranks inside the graph is therefore an autograd function whose
+backward is the matching collective (all-reduce-mean ↔ all-reduce-mean, gather ↔ sum-scatter).
 """
 from __future__ import annotations
 
@@ -57,3 +69,94 @@ def shard_batch(n_items: int, rank: int, world: int) -> slice:
     base, rem = divmod(n_items, world)
     start = rank * base + min(rank, rem)
     return slice(start, start + base + (1 if rank < rem else 0))
+
+
+# --------------------------------------------------------------------------------------------------
+# mode B: global-batch exact
+# --------------------------------------------------------------------------------------------------
+_GLOBAL: Optional[GradBucket] = None
+
+
+class global_batch:
+    """Context: batch-coupled ops executed inside (forward AND backward) reduce over every rank of ``bucket``."""
+
+    def __init__(self, bucket: Optional[GradBucket]):
+        self.bucket = bucket
+
+    def __enter__(self):
+        global _GLOBAL
+        self._prev, _GLOBAL = _GLOBAL, (self.bucket if self.bucket is not None and self.bucket.world > 1 else None)
+        return self
+
+    def __exit__(self, *exc):
+        global _GLOBAL
+        _GLOBAL = self._prev
+        return False
+
+
+def global_batch_active() -> bool:
+    return _GLOBAL is not None
+
+
+def world() -> int:
+    return _GLOBAL.world if _GLOBAL is not None else 1
+
+
+def rank() -> int:
+    return dist.get_rank(_GLOBAL.group) if _GLOBAL is not None else 0
+
+
+def sum_over_ranks_(t: torch.Tensor) -> int:
+    """In-place sum of a (gradient-free) tensor over the ranks of the active global batch; returns the world size
+    (1 and no-op outside the context)."""
+    if _GLOBAL is None:
+        return 1
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_GLOBAL.group)
+    return _GLOBAL.world
+
+
+class _AllReduceMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = x.detach().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=_GLOBAL.group)
+        ctx.group, ctx.n = _GLOBAL.group, _GLOBAL.world
+        return y / _GLOBAL.world
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g / ctx.n
+
+
+def mean_over_ranks(x: torch.Tensor) -> torch.Tensor:
+    """Differentiable mean over ranks (identity outside the context).  Every rank's loss depends on the result, and
+    every rank's gradient is averaged afterwards, so the backward is again the mean over ranks."""
+    return x if _GLOBAL is None else _AllReduceMean.apply(x)
+
+
+class _GatherCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dim):
+        n, r = _GLOBAL.world, dist.get_rank(_GLOBAL.group)
+        shape = list(x.shape)
+        b = shape[dim]
+        shape[dim] = n * b
+        out = x.new_zeros(shape)                        # own block + all-reduce(SUM): works on every backend
+        out.narrow(dim, r * b, b).copy_(x.detach())
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=_GLOBAL.group)
+        ctx.group, ctx.dim, ctx.b, ctx.r = _GLOBAL.group, dim, b, r
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()                      # every rank holds d(its loss)/d(all blocks): sum, keep own block
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g.narrow(ctx.dim, ctx.r * ctx.b, ctx.b).contiguous(), None
+
+
+def gather_cat(x: torch.Tensor, dim: int) -> torch.Tensor:
+    """Differentiable concatenation of every rank's ``x`` along ``dim`` in rank order (identity outside the context);
+    backward = sum over ranks of the incoming gradients, own block kept."""
+    return x if _GLOBAL is None else _GatherCat.apply(x, dim)

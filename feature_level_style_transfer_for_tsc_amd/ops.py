@@ -12,6 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
+from . import dist as _dist
 from ._lib import WSrc, check, ptr, stream_ptr
 from .plan import Plan, Segment, build_plan, pick_mb
 
@@ -529,7 +530,10 @@ def _bn_stats(y: Tensor, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tenso
     if training:
         sums = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
         check(lib.fst_bn_stats(ptr(y), B, C, L, ptr(sums), stream_ptr()), "fst_bn_stats")
-    check(lib.fst_bn_finalize(ptr(sums), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), int(training), B, C, L, eps,
+        B_total = _dist.sum_over_ranks_(sums) * B        # global-batch mode: moments over every rank's samples (SyncBN)
+    else:
+        B_total = B
+    check(lib.fst_bn_finalize(ptr(sums), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), int(training), B_total, C, L, eps,
                               momentum, ptr(stats), stream_ptr()), "fst_bn_finalize")
     return stats
 
@@ -544,8 +548,14 @@ def _bn_backward(dy: Tensor, y: Tensor, out: Optional[Tensor], stats: Tensor, re
     dx = None
     if need_dx:
         dx = torch.empty_like(y)
-        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(red), ptr(dx), B, C, L, int(relu),
-                                   int(training), stream_ptr()), "fst_bn_bwd_apply")
+        red_g, B_total = red, B
+        if training and _dist.global_batch_active():
+            # the two batch means of the backward formula run over every rank's samples; the parameter gradients
+            # (returned below) stay local sums — the gradient bucket averages them like every other parameter
+            red_g = red.clone()
+            B_total = _dist.sum_over_ranks_(red_g) * B
+        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(red_g), ptr(dx), B, C, L, int(relu),
+                                   int(training), B_total, stream_ptr()), "fst_bn_bwd_apply")
     return dx, red[C:], red[:C]                                   # dx, dgamma, dbeta
 
 
@@ -776,26 +786,28 @@ class CouplingInvFn(torch.autograd.Function):
 # CPC InfoNCE
 # --------------------------------------------------------------------------------------------------
 class CPCNceFn(torch.autograd.Function):
-    """nce = −(1/(B·T)) Σ_i Σ_b log_softmax(enc_i·pred_iᵀ)[b,b]; enc_i[b,c] = feat[b,c,t0+i] read in place.
-    ``t0`` is a Python int or a 0-d int32 DEVICE tensor (so a captured hipGraph can vary it between replays)."""
+    """nce = −(1/(B·T)) Σ_i Σ_b log_softmax(enc_i·pred_iᵀ)[b, col_off+b]; enc_i[b,c] = feat[b,c,t0+i] read in place.
+    ``t0`` is a Python int or a 0-d int32 DEVICE tensor (so a captured hipGraph can vary it between replays).
+    ``pred`` is [T, Bc, C] with Bc ≥ B columns (the predictions of every rank in global-batch data parallelism)."""
 
     @staticmethod
-    def forward(ctx, feat: Tensor, pred: Tensor, t0, T: int):
+    def forward(ctx, feat: Tensor, pred: Tensor, t0, T: int, col_off: int = 0):
         lib = _lib.load()
         _lib.require_gpu_tensor(feat, "feat")
         feat, pred = feat.contiguous(), pred.contiguous()
         B, C, L = feat.shape
-        assert pred.shape == (T, B, C)
+        Bc = pred.size(1)
+        assert pred.shape == (T, Bc, C) and 0 <= col_off and col_off + B <= Bc
         t0_dev = t0 if isinstance(t0, torch.Tensor) else None
         t0_host = 0 if t0_dev is not None else int(t0)
         assert t0_dev is None or (t0_dev.dtype == torch.int32 and t0_dev.is_cuda)
         assert t0_host + T <= L
         lse = torch.empty(T, B, device=feat.device, dtype=torch.float32)
         acc = torch.zeros((), device=feat.device, dtype=torch.float32)
-        check(lib.fst_cpc_nce_fwd(feat.data_ptr() + 4 * t0_host, 1, C * L, L, ptr(t0_dev), ptr(pred), T, B, C, ptr(lse),
-                                  ptr(acc), stream_ptr()), "fst_cpc_nce_fwd")
+        check(lib.fst_cpc_nce_fwd(feat.data_ptr() + 4 * t0_host, 1, C * L, L, ptr(t0_dev), ptr(pred), T, B, C, Bc, col_off,
+                                  ptr(lse), ptr(acc), stream_ptr()), "fst_cpc_nce_fwd")
         ctx.save_for_backward(feat, pred, lse)
-        ctx.t0_host, ctx.t0_dev, ctx.T = t0_host, t0_dev, T
+        ctx.t0_host, ctx.t0_dev, ctx.T, ctx.col_off = t0_host, t0_dev, T, col_off
         return acc * (-1.0 / (B * T))
 
     @staticmethod
@@ -808,8 +820,9 @@ class CPCNceFn(torch.autograd.Function):
         dpred = torch.empty_like(pred)
         g = g.contiguous().float()
         check(lib.fst_cpc_nce_bwd(feat.data_ptr() + 4 * t0, 1, C * L, L, ptr(ctx.t0_dev), ptr(pred), ptr(lse), T, B, C,
-                                  ptr(g), dfeat.data_ptr() + 4 * t0, ptr(dpred), stream_ptr()), "fst_cpc_nce_bwd")
-        return dfeat, dpred, None, None
+                                  pred.size(1), ctx.col_off, ptr(g), dfeat.data_ptr() + 4 * t0, ptr(dpred), stream_ptr()),
+              "fst_cpc_nce_bwd")
+        return dfeat, dpred, None, None, None
 
 
 # --------------------------------------------------------------------------------------------------

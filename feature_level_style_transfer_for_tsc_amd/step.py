@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from . import ops
 from .cdan import CDAN, RandomLayer
 from .cpc import CPC
+from . import dist as _dist
 from .dist import GradBucket
 from .os_cnn import OS_CNN, OS_CNN_res, build_layer_with_layer_parameter
 from .structure import generate_layer_parameter_list, layer_parameter_list_input_change, out_channels
@@ -54,7 +55,9 @@ def loss_coefficients(epoch: int) -> Tuple[float, float, float, float]:
 
 
 class ClassifierTrainer:
-    def __init__(self, length: int, in_channel: int, n_class: int, device, bucket: Optional[GradBucket] = None):
+    def __init__(self, length: int, in_channel: int, n_class: int, device, bucket: Optional[GradBucket] = None,
+                 sync: str = "ddp"):
+        self.sync = sync
         fe_spec, clf_spec = specs_for(length, in_channel)
         self.fe = OS_CNN_res(fe_spec).to(device)
         self.clf = OS_CNN(clf_spec, n_class).to(device)
@@ -67,9 +70,10 @@ class ClassifierTrainer:
         return list(self.fe.parameters()) + list(self.clf.parameters())
 
     def step(self, x: torch.Tensor, y: torch.Tensor):
-        logits, _ = self.clf(self.fe(x))
-        loss = F.cross_entropy(logits, y)
-        loss.backward()
+        with _dist.global_batch(self.bucket if self.sync == "global" else None):
+            logits, _ = self.clf(self.fe(x))
+            loss = F.cross_entropy(logits, y)
+            loss.backward()
         if self.bucket is not None:
             self.bucket.all_reduce(self.parameters())
         self.opt_fe.step(); self.opt_clf.step()
@@ -100,8 +104,13 @@ class JointTrainer:
            "nf": 0.001, "noise": 0.005, "ad_net": 0.001, "fd_s": 0.001}       # train_and_test.py:97-106
 
     def __init__(self, cfg: JointConfig, device, bucket: Optional[GradBucket] = None, fe_t_spec=None, clf_spec=None,
-                 fe_s_spec=None):
-        self.cfg, self.device, self.bucket = cfg, device, bucket
+                 fe_s_spec=None, sync: str = "ddp"):
+        """``sync`` (with a bucket): "ddp" = per-rank batch statistics (SURVEY §8e mode A); "global" = every
+        batch-coupled quantity over the samples of all ranks (mode B, eager only) — N ranks reproduce the
+        single-process step on the concatenated batch."""
+        if sync not in ("ddp", "global"):
+            raise ValueError(f"sync must be 'ddp' or 'global', got {sync!r}")
+        self.cfg, self.device, self.bucket, self.sync = cfg, device, bucket, sync
         if fe_t_spec is None:
             fe_t_spec, clf_spec = specs_for(cfg.L_t, cfg.C_in_t)
             fe_s_spec, _ = specs_for(cfg.L_s, cfg.C_in_s)
@@ -238,7 +247,8 @@ class JointTrainer:
         """Everything device-side and shape-static, so it runs eagerly or under hipGraph capture unchanged.
         Two halves with the step's only collectives between them (so a captured step never contains RCCL):
         A = forward, GradNorm partial backwards, full backward;  B = GradNorm weight update + optimisers."""
-        mid = self._step_part_a(x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios)
+        with _dist.global_batch(self.bucket if self.sync == "global" else None):
+            mid = self._step_part_a(x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios)
         self._reduce(mid)
         return self._step_part_b(mid)
 
@@ -261,6 +271,13 @@ class JointTrainer:
             with ops.partial_backward():
                 g_t = [torch.autograd.grad(lt[i], sh_t, retain_graph=True) for i in range(2)]
                 g_s = [torch.autograd.grad(ls[i], sh_s, retain_graph=(i < 2)) for i in range(3)]
+            if _dist.global_batch_active():
+                # mode B: the norms are those of the GLOBAL per-loss gradients (mean over ranks), not means of norms
+                flat = torch.cat([g.reshape(-1) for gs in g_t + g_s for g in gs])
+                flat = flat / _dist.sum_over_ranks_(flat)
+                it = iter(torch.split(flat, [g.numel() for gs in g_t + g_s for g in gs]))
+                g_t = [[next(it).view_as(g) for g in gs] for gs in g_t]
+                g_s = [[next(it).view_as(g) for g in gs] for gs in g_s]
             base_t = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_t])
             base_s = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_s])
         report = {k: v.detach() for k, v in L.items()}
@@ -321,6 +338,8 @@ class JointTrainer:
         at capture, so the warm-up runs until their call counters saturate (20 calls = 10 steps — quirk Q7); the
         epoch-dependent loss coefficients are baked too: re-capture when ``loss_coefficients(epoch)`` changes.
         Single GPU: one graph.  Data parallel: two graphs (A, B) with the eager RCCL all-reduce between them."""
+        if self.sync == "global" and self.bucket is not None and self.bucket.world > 1:
+            raise RuntimeError("sync='global' (mode B) puts collectives inside autograd: run it eagerly with step()")
         dev = self.device
         self._g_in = {"x_t": x_t.clone(), "y_t": y_t.clone(), "x_s": x_s.clone(), "y_s": y_s.clone(),
                       "t": torch.zeros(2, dtype=torch.int32, device=dev), "r": torch.ones(2, device=dev)}

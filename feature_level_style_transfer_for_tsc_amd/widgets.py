@@ -7,6 +7,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import dist as _dist
 from . import ops
 from .cdan import calc_coeff as _calc_coeff_cdan, grl_hook
 
@@ -152,8 +153,9 @@ class NoiseTransfer(nn.Module):
         hipGraph passes static buffers that the host refreshes (via ``advance``) before every replay."""
         if ratios is None:
             ratios = self.advance(target_noise_batch.size(0), source_noise_batch.size(0))
-        new_target = self.target_avg + ratios[0] * torch.mean(target_noise_batch, dim=0)
-        new_source = self.source_avg + ratios[1] * torch.mean(source_noise_batch, dim=0)
+        # (global-batch data parallelism: the batch means run over every rank's samples)
+        new_target = self.target_avg + ratios[0] * _dist.mean_over_ranks(torch.mean(target_noise_batch, dim=0))
+        new_source = self.source_avg + ratios[1] * _dist.mean_over_ranks(torch.mean(source_noise_batch, dim=0))
         general_distance = new_target - new_source
         learned = self.activation_selu(self.apply_learnable_weight(general_distance))   # unbatched [C, L] conv
         self.target_avg.copy_(new_target.detach())                # state is kept detached, in place

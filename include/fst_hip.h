@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 2
+#define FST_ABI_VERSION 3
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -128,18 +128,21 @@ int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, v
  * stats layout (float[4*C]): mean | invstd | scale | shift   (scale = γ·invstd, shift = β − mean·scale)
  * ------------------------------------------------------------------------------------------- */
 int fst_bn_stats(const float* y, int B, int C, int L, float* sums /* [2*C], zeroed by caller */, void* stream);
+/* sums = (Σx, Σx²) over B_total·L samples per channel: B_total is the batch the moments run over — the local batch,
+ * or in global-batch data parallelism (SyncBN) the sum of every rank's batch after the caller all-reduced sums. */
 int fst_bn_finalize(const float* sums, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int train,
-                    int B, int C, int L, float eps, float momentum, float* stats, void* stream);
+                    int B_total, int C, int L, float eps, float momentum, float* stats, void* stream);
 /* out = act(y*scale + shift (+ res*res_scale + res_shift | + res)) */
 int fst_bn_apply(const float* y, const float* stats, const float* res, const float* res_stats,
                  float* out, int B, int C, int L, int relu, void* stream);
 /* reductions for backward: red[c] = Σ dyʹ, red[C+c] = Σ dyʹ·x̂, with dyʹ = dy·[out>0] when relu */
 int fst_bn_bwd_reduce(const float* dy, const float* y, const float* out, const float* stats,
                       int B, int C, int L, int relu, float* red /* [2*C] zeroed */, void* stream);
-/* dx = scale·(dyʹ − red0/N − x̂·red1/N) in train mode, scale·dyʹ in eval mode */
+/* dx = scale·(dyʹ − red0/N − x̂·red1/N) in train mode, scale·dyʹ in eval mode; N = B_total·L.  B is the batch of
+ * the tensors (launch shape); B_total >= B the batch red was summed over (= B, or all ranks' batches for SyncBN). */
 int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
-                     float* dx, int B, int C, int L, int relu, int train, void* stream);
+                     float* dx, int B, int C, int L, int relu, int train, int B_total, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * WaveGlow pieces — Simplified_NF_WaveGlow.py
@@ -170,12 +173,16 @@ int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, con
  * (a strided view of the [B,C,L] feature tensor); pred is [T,B,C] contiguous; lse [T,B] is kept
  * for backward.  gout is the DEVICE scalar d loss / d nce.  t0_dev (optional DEVICE int32 scalar) adds
  * t0_dev[0]·s_i elements to enc/denc, so the random start index can change between hipGraph replays.
+ * Rows (B encodings of this rank) and columns (Bc predictions) may differ: "global batch" data parallelism scores
+ * the local rows against the predictions gathered from every rank, the positives at columns col_off + b.
  * ------------------------------------------------------------------------------------------- */
 int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
-                    const float* pred, int T, int B, int C, float* lse, float* nce_sum /* scalar, zeroed */, void* stream);
+                    const float* pred /* [T][Bc][C] */, int T, int B, int C,
+                    int Bc /* columns = negatives; = B on one GPU */, int col_off /* column of row 0's positive */,
+                    float* lse /* [T][B] */, float* nce_sum /* scalar, zeroed */, void* stream);
 int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
-                    const float* pred, const float* lse, int T, int B, int C, const float* gout,
-                    float* denc /* same strides as enc */, float* dpred, void* stream);
+                    const float* pred, const float* lse, int T, int B, int C, int Bc, int col_off, const float* gout,
+                    float* denc /* same strides as enc */, float* dpred /* [T][Bc][C] */, void* stream);
 
 #ifdef __cplusplus
 }

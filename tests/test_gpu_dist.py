@@ -15,6 +15,31 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def _guarded(fn):
+    """A worker that dies with an exception would leave the parent waiting on the queue: report it instead."""
+    def run(rank, world, port, q):
+        try:
+            fn(rank, world, port, q)
+        except BaseException:                                              # noqa: BLE001 — forwarded to the parent
+            import traceback
+            q.put((rank, "worker failed", traceback.format_exc()))
+            raise
+    run.__name__ = fn.__name__
+    return run
+
+
+def _collect(q, world, procs, timeout=300):
+    out = []
+    for _ in range(world):
+        item = q.get(timeout=timeout)
+        assert not (len(item) == 3 and item[1] == "worker failed"), f"rank {item[0]}:\n{item[2]}"
+        out.append(item)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return sorted(out, key=lambda t: t[0])
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,20 +71,112 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _run_worker(name, rank, world, port, q):
+    _guarded(globals()[name])(rank, world, port, q)
+
+
 def test_two_rank_replicas_stay_identical():
     world, port = 2, 29633
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_run_worker, args=("_worker", r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=600) for _ in range(world))
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    out = _collect(q, world, procs)
     (_, e0, g0, n0, w0, l0), (_, e1, g1, n1, w1, l1) = out
     assert e0 == e1, "replicas diverged in eager DP steps"
     assert g0 == g1, "replicas diverged through the captured DP step"
     assert n0 == n1 == 2                                                 # two graphs with the collectives between
     assert abs(w0 - 7.0) < 1e-4 and w0 == w1                             # GradNorm weights renormalised, in sync
     assert l0 != l1                                                      # ranks really saw different batches
+
+
+# --------------------------------------------------------------------------------------------------
+# mode B ("global-batch exact"): 2 ranks x B/2 samples == 1 process x B samples
+# --------------------------------------------------------------------------------------------------
+def _build_small_trainer(fst, dev, bucket, sync):
+    g = dict(np.load(os.path.join(GOLDEN, "joint_small.npz"), allow_pickle=False))
+    meta = json.loads(str(g["meta"]))
+    tup = lambda lp: [[tuple(t) for t in l] for l in lp]
+    sub = lambda prefix: {k[len(prefix):]: torch.tensor(v) for k, v in g.items() if k.startswith(prefix)}
+    cfg = fst.JointConfig(L_t=meta["L_t"], C_in_t=meta["C_in_t"], L_s=meta["L_s"], C_in_s=meta["C_in_s"],
+                          n_class_t=meta["ncls_t"], n_class_s=meta["ncls_s"], nf_channels=meta["nf"][2],
+                          cpc_hidden=meta["cpc"][1], cdan_dim=64, ad_hidden=32, dropout_p=0.0)
+    tr = fst.JointTrainer(cfg, dev, bucket, fe_t_spec=tup(meta["lp_t"]), clf_spec=tup(meta["lp_clf"]),
+                          fe_s_spec=tup(meta["lp_s"]), sync=sync)
+    tr.load_params({name: sub(f"sd0.{name}.") for name in tr.MODULES}, [torch.tensor(g["m0"]), torch.tensor(g["m1"])])
+    return tr, meta
+
+
+def _global_data(meta, n):
+    gen = torch.Generator().manual_seed(4242)
+    mk = lambda C, L, k: (torch.randn(n, C, L, generator=gen), torch.randint(k, (n,), generator=gen))
+    return mk(meta["C_in_t"], meta["L_t"], meta["ncls_t"]), mk(meta["C_in_s"], meta["L_s"], meta["ncls_s"])
+
+
+def _one_step_with_grads(tr, x_t, y_t, x_s, y_s):
+    grads = {}
+    tr.on_grads_ready = lambda: grads.update(
+        {f"{k}.{n}": p.grad.detach().float().cpu().clone() for k in tr.MODULES for n, p in tr.m[k].named_parameters()
+         if p.grad is not None})
+    rep = tr.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=(2, 5))
+    torch.cuda.synchronize()
+    losses = {k: float(rep[k]) for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s")}
+    return losses, rep["logit_t"].float().cpu(), grads, rep["w_t"].float().cpu(), rep["w_s"].float().cpu()
+
+
+def _worker_global(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import feature_level_style_transfer_for_tsc_amd as fst
+    dev = torch.device("cuda:0")
+    tr, meta = _build_small_trainer(fst, dev, fst.GradBucket(), "global")
+    B = meta["B"]                                                         # per rank; the global batch is world*B
+    (x_t, y_t), (x_s, y_s) = _global_data(meta, world * B)
+    sl = slice(rank * B, (rank + 1) * B)
+    losses, logit_t, grads, w_t, w_s = _one_step_with_grads(tr, x_t[sl].to(dev), y_t[sl].to(dev), x_s[sl].to(dev), y_s[sl].to(dev))
+    q.put((rank, losses, logit_t.numpy(), {k: v.numpy() for k, v in grads.items()}, w_t.numpy(), w_s.numpy()))
+    dist.destroy_process_group()
+
+
+def test_global_batch_mode_reproduces_the_single_process_step():
+    """SyncBN + CPC negatives from every rank + global NoiseTransfer means + CDAN's global batch sums + GradNorm on
+    the averaged per-loss gradients: two ranks with half the batch each give the losses, logits, accumulated
+    gradients (after the bucket) and GradNorm weights of one process on the whole batch."""
+    world, port = 2, 29641
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run_worker, args=("_worker_global", r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = _collect(q, world, procs)
+
+    import feature_level_style_transfer_for_tsc_amd as fst
+    dev = torch.device("cuda:0")
+    tr, meta = _build_small_trainer(fst, dev, None, "ddp")
+    B = meta["B"]
+    (x_t, y_t), (x_s, y_s) = _global_data(meta, world * B)
+    ref_losses, ref_logits, ref_grads, ref_w_t, ref_w_s = _one_step_with_grads(tr, x_t.to(dev), y_t.to(dev), x_s.to(dev), y_s.to(dev))
+
+    # per-sample means: the global loss is the mean of the ranks' local losses; batch sums / global quantities are
+    # reported identically by every rank
+    local_mean = ("nf_t", "nf_s", "ce_t", "ce_s", "ce_s2t2s", "sl_t", "sl_s", "fd_s")
+    for k in local_mean:
+        got = sum(o[1][k] for o in out) / world
+        assert abs(got - ref_losses[k]) <= 1e-4 * max(1.0, abs(ref_losses[k])), (k, got, ref_losses[k])
+    for o in out:
+        assert abs(o[1]["cdan"] - ref_losses["cdan"]) <= 1e-4 * max(1.0, abs(ref_losses["cdan"])), (o[1]["cdan"], ref_losses["cdan"])
+    for rank, _, logit_t, grads, w_t, w_s in out:
+        want = ref_logits[rank * B: (rank + 1) * B].numpy()
+        assert np.abs(logit_t - want).max() <= 1e-4 * max(1.0, np.abs(want).max()), "logits (SyncBN) differ"
+        assert np.abs(w_t - ref_w_t.numpy()).max() <= 1e-4 and np.abs(w_s - ref_w_s.numpy()).max() <= 1e-4, "GradNorm weights"
+        assert set(grads) == set(ref_grads)
+        by_mod = {}
+        for k, gr in grads.items():
+            mod = k.split(".")[0]
+            by_mod.setdefault(mod, [0.0, 0.0])
+            ref = ref_grads[k].numpy()
+            by_mod[mod][0] = max(by_mod[mod][0], float(np.abs(gr - ref).max()))
+            by_mod[mod][1] = max(by_mod[mod][1], float(np.abs(ref).max()))
+        for mod, (err, scale) in by_mod.items():
+            assert err <= 2e-3 * max(scale, 1e-6), f"rank {rank}: gradients of {mod} differ: {err:.3e} vs scale {scale:.3e}"

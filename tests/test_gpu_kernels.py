@@ -260,6 +260,24 @@ def test_cpc_nce(B, C, L, T, t0):
     assert_close(fd.grad, feat.grad, 5e-5, "dfeat"); assert_close(pd.grad, pred.grad, 5e-5, "dpred")
 
 
+@pytest.mark.parametrize("B,Bc,off,C,L,T,t0", [(4, 12, 4, 6, 20, 10, 3), (37, 111, 74, 50, 128, 64, 9), (64, 256, 128, 50, 512, 256, 7)])
+def test_cpc_nce_rows_against_gathered_columns(B, Bc, off, C, L, T, t0):
+    """Global-batch data parallelism: B local rows scored against Bc gathered predictions, positives at column off+b."""
+    g = torch.Generator().manual_seed(B + Bc)
+    feat = torch.randn(B, C, L, generator=g, dtype=torch.float64, requires_grad=True)
+    pred = (torch.randn(T, Bc, C, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    enc = feat[:, :, t0:t0 + T].permute(2, 0, 1)                  # [T, B, C]
+    lsm = F.log_softmax(torch.bmm(enc, pred.transpose(1, 2)), dim=-1)          # [T, B, Bc]
+    pos = lsm[:, torch.arange(B), off + torch.arange(B)]
+    nce = -pos.sum() / (B * T)
+    (nce * 0.9).backward()
+    fd, pd = feat.detach().float().to(DEV).requires_grad_(True), pred.detach().float().to(DEV).requires_grad_(True)
+    got = ops.CPCNceFn.apply(fd, pd, t0, T, off)
+    (got * 0.9).backward()
+    assert abs(got.item() - nce.item()) <= 2e-5 * max(1.0, abs(nce.item()))
+    assert_close(fd.grad, feat.grad, 5e-5, "dfeat"); assert_close(pd.grad, pred.grad, 5e-5, "dpred")
+
+
 def test_fixed_matmul(arithmetic):
     g = torch.Generator().manual_seed(9)
     Bx, D, O = 7, 640, 64
