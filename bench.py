@@ -60,6 +60,25 @@ def cpu_baseline(L: int, pairs: int, steps: int):
                       f"({steps * dt:.0f} s of CPU work), autograd anomaly mode off, {dt:.2f} s/step"}
 
 
+def classifier_step_rate(fst, device, B: int, L: int, steps: int = 30, warmup: int = 5):
+    """S1 of SURVEY §8d: the classifier-only step (FE -> classifier -> CE -> backward -> RMSprop,
+    train_and_test.py:153-171) on the same synthetic batch shape; eager launches, HIP-event timed."""
+    tr = fst.ClassifierTrainer(L, 1, 4, device)
+    x, y = synthetic_batch(B, 1, L, 4, device, 3000)
+    for _ in range(warmup):
+        tr.step(x, y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        tr.step(x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"value": 1e3 * B / ms, "unit": "samples/s", "ms_per_step": ms, "steps": steps,
+            "workload": f"S1 classifier-only step (OS_CNN_res + OS_CNN + CE + RMSprop), univariate L={L}, batch {B}, eager"}
+
+
 def kernel_peak(key: str) -> float:
     """Dense MFMA peak (algorithmic TFLOP/s) of the instruction a conv-engine kernel is built on."""
     bf3 = "bf3" in key or (key.startswith("conv_wgrad_kernel") and key.rstrip(">").endswith("true"))
@@ -202,6 +221,8 @@ def main() -> None:
                                "omni-scale window kernel and everything pointwise in f32") if ops.MATH == "bf16x3" else "f32 MFMA",
                 "losses": {k: float(rep[k]) for k in ("nf_t", "nf_s", "ce_t", "ce_s", "sl_t", "cdan")},
                 "roofline": roofline}
+        if world == 1:
+            line["s1_classifier_step"] = classifier_step_rate(fst, device, args.batch, args.length)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.length, args.cpu_pairs, args.cpu_steps)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -237,6 +237,69 @@ class JointTrainer:
         aux = {"logit_t": logit_t, "logit_s": logit_s, "logit_s2t": logit_s2t, "feat_t": feat_t, "feat_s2t": feat_s2t}
         return losses, aux
 
+    # ------------------------------------------------------------------ pre-training phases (train_and_test.py:141-494)
+    PHASES = {                                                                       # phase -> optimisers stepped
+        "target_pretrain": ("fe_t", "clf_t", "cpc"),                                 # :143-171  CE_t + CPC_t
+        "source_pretrain": ("fe_s", "dimunif", "clf_s"),                             # :183-209  CE_s
+        "ssl_with_ce": ("fe_t", "clf_t", "cpc", "fe_s", "dimunif", "clf_s"),         # :232-275  every 50th epoch
+        "ssl": ("fe_t", "cpc", "fe_s", "dimunif"),                                   # :296-348
+        "nf_with_ce": ("fe_t", "clf_t", "fe_s", "dimunif", "clf_s", "nf", "cpc"),    # :388-431  every 75th epoch
+        "nf": ("fe_t", "fe_s", "dimunif", "nf"),                                     # :457-494  features detached
+    }
+
+    def phase_losses(self, phase: str, x_t, y_t, x_s, y_s, t_samples=(None, None)):
+        """(total, losses) of one batch of a pre-training phase — sub-graphs of the joint step on the same modules.
+        "ssl" runs both classifiers in train mode (their BatchNorm running statistics move) although nothing of theirs
+        is in the total; "nf" detaches the features, so only the flow receives gradients."""
+        if phase not in self.PHASES:
+            raise ValueError(f"unknown phase {phase!r}; one of {sorted(self.PHASES)}")
+        m, L = self.m, {}
+        if phase == "target_pretrain":
+            feat_t = m["fe_t"](x_t)
+            L["sl_t"] = m["cpc"](feat_t, t_samples[0])
+            L["ce_t"] = F.cross_entropy(m["clf_t"](feat_t)[0], y_t)
+            return L["ce_t"] + L["sl_t"], L
+        if phase == "source_pretrain":
+            feat_s = m["dimunif"](m["fe_s"](x_s))
+            L["ce_s"] = F.cross_entropy(m["clf_s"](feat_s)[0], y_s)
+            return L["ce_s"], L
+        feat_t = m["fe_t"](x_t)
+        feat_s = m["dimunif"](m["fe_s"](x_s))
+        if phase == "nf":
+            feat_t, feat_s = feat_t.detach(), feat_s.detach()
+        else:
+            L["sl_t"] = m["cpc"](feat_t, t_samples[0])
+            L["ce_t"] = F.cross_entropy(m["clf_t"](feat_t)[0], y_t)
+            L["sl_s"] = m["cpc"](feat_s, t_samples[1])
+            L["ce_s"] = F.cross_entropy(m["clf_s"](feat_s)[0], y_s)
+        if phase == "ssl_with_ce":
+            return L["sl_t"] + L["sl_s"] + 0.8 * L["ce_t"] + 1.2 * L["ce_s"], L
+        if phase == "ssl":
+            return L["sl_t"] + L["sl_s"], L
+        L["nf_t"], L["nf_s"] = self.nf_loss(m["nf"](feat_t)), self.nf_loss(m["nf"](feat_s))
+        if phase == "nf_with_ce":
+            return L["nf_t"] + L["nf_s"] + 5 * L["ce_t"] + 5 * L["ce_s"] + 3 * L["sl_t"] + 3 * L["sl_s"], L
+        return L["nf_t"] + L["nf_s"], L
+
+    def phase_step(self, phase: str, x_t, y_t, x_s, y_s, t_samples=(None, None)):
+        """One batch of a pre-training phase: forward, backward, the phase's optimisers, zero_grad (eager)."""
+        with _dist.global_batch(self.bucket if self.sync == "global" else None):
+            with ops.pack_cache(), self.m["nf"].shared_fold():
+                total, L = self.phase_losses(phase, x_t, y_t, x_s, y_s, t_samples)
+                for o in self.opts.values():
+                    o.zero_grad(set_to_none=True)
+                self.opt_cpc.zero_grad(set_to_none=True)
+                total.backward()
+        if self.bucket is not None:
+            self.bucket.all_reduce(self.parameters())
+        if self.on_grads_ready is not None:
+            self.on_grads_ready()
+        for k in self.PHASES[phase]:
+            (self.opt_cpc if k == "cpc" else self.opts[k]).step()
+        report = {k: v.detach() for k, v in L.items()}
+        report["total"] = total.detach()
+        return report
+
     # ------------------------------------------------------------------ one optimisation step (:645-766)
     def step(self, x_t, y_t, x_s, y_s, epoch: int = 0, t_samples=(None, None)):
         """Eager step.  ``t_samples``: the two CPC start indices (drawn like the reference if None)."""

@@ -255,6 +255,8 @@ def main() -> None:
     init_t = init_s = None
     for m in M.values():
         m.train()
+    import copy
+    sd0_all = {name: copy.deepcopy(m.state_dict()) for name, m in M.items()}        # for the pre-training phases below
     for step in range(2):
         x_t, y_t = torch.randn(B, C_in_t, L_t), torch.randint(ncls_t, (B,))
         x_s, y_s = torch.randn(B, C_in_s, L_s), torch.randint(ncls_s, (B,))
@@ -355,6 +357,75 @@ def main() -> None:
     for k in ("sd1.fd_s.model.2.weight", "s0.grad.fd_s.model.2.weight"):      # 1.3 MB each; the other fd_s tensors pin the update
         joint.pop(k)
     save("joint_small", **joint)
+
+    # ---------------------------------------------------------------- pre-training phases (train_and_test.py:141-494)
+    # One batch of each phase body, every time from the joint fixture's initial state sd0 and on its step-0 batch, with
+    # fresh optimisers as at the top of train(): losses, every accumulated gradient, and the BatchNorm running mean of
+    # the target classifier's first layer after the step (phase "ssl" runs the classifiers in train mode without
+    # optimising them, so their running statistics still move).
+    x_t, y_t = torch.tensor(joint["s0.x_t"]), torch.tensor(joint["s0.y_t"])
+    x_s, y_s = torch.tensor(joint["s0.x_s"]), torch.tensor(joint["s0.y_s"])
+    seeds = (500, 501)
+    phases = {"meta": np.array(json.dumps({"phases": ["target_pretrain", "source_pretrain", "ssl_with_ce", "ssl",
+                                                      "nf_with_ce", "nf"], "t_samples": [int(v) for v in joint["s0.t_samples"]]}))}
+
+    def cpc_pair(feat_t, feat_s):
+        torch.manual_seed(seeds[0]); a = M["cpc"](feat_t)
+        torch.manual_seed(seeds[1]); b_ = M["cpc"](feat_s)
+        return a, b_
+
+    for phase in ("target_pretrain", "source_pretrain", "ssl_with_ce", "ssl", "nf_with_ce", "nf"):
+        for name, m in M.items():
+            m.load_state_dict(copy.deepcopy(sd0_all[name]))
+            m.train()
+            for p_ in m.parameters():
+                p_.grad = None
+        opts = {k: torch.optim.RMSprop(M[k].parameters(), lr=lr) for k, lr in rms_lr.items()}
+        opt_cpc = torch.optim.Adam(M["cpc"].parameters(), lr=0.002)
+        L = {}
+        if phase == "target_pretrain":                                              # :143-171
+            feat_t = M["fe_t"](x_t)
+            torch.manual_seed(seeds[0]); L["sl_t"] = M["cpc"](feat_t)
+            L["ce_t"] = ce(M["clf_t"](feat_t)[0], y_t)
+            total, stepped = L["ce_t"] + L["sl_t"], ["fe_t", "clf_t", "cpc"]
+        elif phase == "source_pretrain":                                            # :183-209
+            feat_s = M["dimunif"](M["fe_s"](x_s))
+            L["ce_s"] = ce(M["clf_s"](feat_s)[0], y_s)
+            total, stepped = L["ce_s"], ["fe_s", "dimunif", "clf_s"]
+        elif phase in ("ssl_with_ce", "ssl", "nf_with_ce"):                          # :232-275, :296-348, :388-431
+            feat_t = M["fe_t"](x_t)
+            feat_s = M["dimunif"](M["fe_s"](x_s))
+            torch.manual_seed(seeds[0]); L["sl_t"] = M["cpc"](feat_t)
+            L["ce_t"] = ce(M["clf_t"](feat_t)[0], y_t)
+            torch.manual_seed(seeds[1]); L["sl_s"] = M["cpc"](feat_s)
+            L["ce_s"] = ce(M["clf_s"](feat_s)[0], y_s)
+            if phase == "ssl_with_ce":
+                total = L["sl_t"] + L["sl_s"] + 0.8 * L["ce_t"] + 1.2 * L["ce_s"]
+                stepped = ["fe_t", "clf_t", "cpc", "fe_s", "dimunif", "clf_s"]
+            elif phase == "ssl":
+                total, stepped = L["sl_t"] + L["sl_s"], ["fe_t", "cpc", "fe_s", "dimunif"]
+            else:
+                L["nf_t"], L["nf_s"] = nf_loss(M["nf"](feat_t)), nf_loss(M["nf"](feat_s))
+                total = L["nf_t"] + L["nf_s"] + 5 * L["ce_t"] + 5 * L["ce_s"] + 3 * L["sl_t"] + 3 * L["sl_s"]
+                stepped = ["fe_t", "clf_t", "fe_s", "dimunif", "clf_s", "nf", "cpc"]
+        else:                                                                       # "nf": :457-494, features detached
+            feat_t = M["fe_t"](x_t).detach_()
+            feat_s = M["dimunif"](M["fe_s"](x_s)).detach_()
+            L["nf_t"], L["nf_s"] = nf_loss(M["nf"](feat_t)), nf_loss(M["nf"](feat_s))
+            total, stepped = L["nf_t"] + L["nf_s"], ["fe_t", "fe_s", "dimunif", "nf"]
+        total.backward()
+        for k, v in L.items():
+            phases[f"{phase}.loss.{k}"] = np.array(float(v))
+        phases[f"{phase}.total"] = np.array(float(total))
+        for name in ("fe_t", "clf_t", "fe_s", "dimunif", "clf_s", "nf", "cpc"):
+            phases.update(grads_np(M[name], f"{phase}.grad.{name}."))
+        for k in stepped:
+            (opt_cpc if k == "cpc" else opts[k]).step()
+        phases[f"{phase}.stepped"] = np.array(json.dumps(stepped))
+        phases[f"{phase}.after.clf_t.bn_mean0"] = M["clf_t"].state_dict()["net.0.bn.running_mean"].numpy().copy()
+        phases[f"{phase}.after.fe_t.w0"] = M["fe_t"].state_dict()["net_1.net.net.0.conv1d.weight"].numpy().copy()
+        phases[f"{phase}.after.clf_t.hidden"] = M["clf_t"].state_dict()["hidden.weight"].numpy().copy()
+    save("phases_small", **phases)
 
 
 if __name__ == "__main__":

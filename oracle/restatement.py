@@ -477,6 +477,65 @@ class JointStep:
         aux = {"logit_t": logit_t, "logit_s": logit_s, "logit_s2t": logit_s2t, "feat_t": feat_t, "feat_s2t": feat_s2t}
         return losses, aux
 
+    # the pre-training phases of train() — sub-graphs of the joint step on the same modules and optimisers
+    PHASES = {                                                                       # phase -> optimisers stepped
+        "target_pretrain": ("fe_t", "clf_t", "cpc"),                                 # train_and_test.py:143-171
+        "source_pretrain": ("fe_s", "dimunif", "clf_s"),                             # :183-209
+        "ssl_with_ce": ("fe_t", "clf_t", "cpc", "fe_s", "dimunif", "clf_s"),         # :232-275 (every 50th epoch)
+        "ssl": ("fe_t", "cpc", "fe_s", "dimunif"),                                   # :296-348
+        "nf_with_ce": ("fe_t", "clf_t", "fe_s", "dimunif", "clf_s", "nf", "cpc"),    # :388-431 (every 75th epoch)
+        "nf": ("fe_t", "fe_s", "dimunif", "nf"),                                     # :457-494 (features detached)
+    }
+
+    def phase_losses(self, phase: str, x_t, y_t, x_s, y_s, t_samples=(None, None)):
+        """(total, losses) of one batch of a pre-training phase.  Note "ssl": both classifiers run in train mode
+        (their BatchNorm running statistics move) although their losses are not in the total and they are not
+        stepped (:308-324); "nf": the features are detached, so only the flow receives gradients (:467-471)."""
+        m, L = self.m, {}
+        if phase == "target_pretrain":
+            feat_t = feature_extractor(x_t, m["fe_t"], self.fe_t_spec, True)
+            L["sl_t"] = cpc_nce(feat_t, m["cpc"], self.T, t_samples[0])
+            L["ce_t"] = F.cross_entropy(classifier(feat_t, m["clf_t"], self.clf_spec, True)[0], y_t)
+            return L["ce_t"] + L["sl_t"], L
+        if phase == "source_pretrain":
+            feat_s = dimension_unification(feature_extractor(x_s, m["fe_s"], self.fe_s_spec, True), m["dimunif"])
+            L["ce_s"] = F.cross_entropy(classifier(feat_s, m["clf_s"], self.clf_spec, True)[0], y_s)
+            return L["ce_s"], L
+        feat_t = feature_extractor(x_t, m["fe_t"], self.fe_t_spec, True)
+        feat_s = dimension_unification(feature_extractor(x_s, m["fe_s"], self.fe_s_spec, True), m["dimunif"])
+        if phase == "nf":
+            feat_t, feat_s = feat_t.detach(), feat_s.detach()
+        else:
+            L["sl_t"] = cpc_nce(feat_t, m["cpc"], self.T, t_samples[0])
+            L["ce_t"] = F.cross_entropy(classifier(feat_t, m["clf_t"], self.clf_spec, True)[0], y_t)
+            L["sl_s"] = cpc_nce(feat_s, m["cpc"], self.T, t_samples[1])
+            L["ce_s"] = F.cross_entropy(classifier(feat_s, m["clf_s"], self.clf_spec, True)[0], y_s)
+        if phase == "ssl_with_ce":
+            return L["sl_t"] + L["sl_s"] + 0.8 * L["ce_t"] + 1.2 * L["ce_s"], L
+        if phase == "ssl":
+            return L["sl_t"] + L["sl_s"], L
+        L["nf_t"] = waveglow_loss(waveglow_forward(feat_t, m["nf"], self.n_flows))
+        L["nf_s"] = waveglow_loss(waveglow_forward(feat_s, m["nf"], self.n_flows))
+        if phase == "nf_with_ce":
+            return L["nf_t"] + L["nf_s"] + 5 * L["ce_t"] + 5 * L["ce_s"] + 3 * L["sl_t"] + 3 * L["sl_s"], L
+        if phase == "nf":
+            return L["nf_t"] + L["nf_s"], L
+        raise ValueError(f"unknown phase {phase!r}")
+
+    def phase_step(self, phase: str, x_t, y_t, x_s, y_s, t_samples=(None, None)):
+        total, L = self.phase_losses(phase, x_t, y_t, x_s, y_s, t_samples)
+        total.backward()
+        for k in self.PHASES[phase]:
+            (self.opt_cpc if k == "cpc" else self.opts[k]).step()
+        report = {k: v.detach().clone() for k, v in L.items()}
+        report["total"] = total.detach().clone()
+        return report
+
+    def zero_grad(self):
+        for o in self.opts.values():
+            o.zero_grad()
+        self.opt_cpc.zero_grad()
+
     def step(self, x_t, y_t, x_s, y_s, epoch: int = 0, t_samples=(None, None)):
         L, aux = self.forward_losses(x_t, y_t, x_s, y_s, t_samples)
         report = {k: v.detach().clone() for k, v in L.items()}

@@ -229,6 +229,43 @@ def test_joint_step_golden():
         check_grads(tr.m[name], sub(g, f"s0.grad.{name}."), 2e-3, f"Q3 {name} ", grads=grads[name])
 
 
+@pytest.mark.parametrize("phase", ["target_pretrain", "source_pretrain", "ssl_with_ce", "ssl", "nf_with_ce", "nf"])
+def test_pretraining_phase_steps_golden(phase):
+    """One batch of every pre-training phase of the reference's train() (train_and_test.py:141-494) from the joint
+    fixture's state: losses, which modules receive gradients and their values, the target classifier's BatchNorm
+    running mean afterwards (phase "ssl" moves it without training the classifier), which optimisers moved."""
+    g, ph = load("joint_small"), load("phases_small")
+    tr = _joint_trainer(g)
+    args = [torch.tensor(g[f"s0.{k}"], device=DEV) for k in ("x_t", "y_t", "x_s", "y_s")]
+    ts = tuple(int(v) for v in g["s0.t_samples"])
+    assert list(tr.PHASES[phase]) == json.loads(str(ph[f"{phase}.stepped"]))
+    grads = {}
+
+    def capture():
+        for name in tr.MODULES:
+            grads[name] = {n: p.grad.detach().clone() for n, p in tr.m[name].named_parameters() if p.grad is not None}
+    tr.on_grads_ready = capture
+    hidden0 = tr.m["clf_t"].hidden.weight.detach().clone()
+    nf0 = tr.m["nf"].WN[0].end.weight.detach().clone()
+    rep = tr.phase_step(phase, *args, t_samples=ts)
+    want_total = float(ph[f"{phase}.total"])
+    assert abs(rep["total"].item() - want_total) <= 1e-4 * max(1.0, abs(want_total)), (rep["total"].item(), want_total)
+    for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s"):
+        if f"{phase}.loss.{k}" in ph:
+            want = float(ph[f"{phase}.loss.{k}"])
+            assert abs(rep[k].item() - want) <= 1e-4 * max(1.0, abs(want)), (k, rep[k].item(), want)
+        else:
+            assert k not in rep
+    for name in ("fe_t", "clf_t", "fe_s", "dimunif", "clf_s", "nf", "cpc"):
+        want = sub(ph, f"{phase}.grad.{name}.")
+        assert set(grads[name]) == set(want), (phase, name, set(grads[name]) ^ set(want))
+        if want:
+            check_grads(tr.m[name], want, 2e-3, f"{phase} {name} ", grads=grads[name])
+    close(tr.m["clf_t"].state_dict()["net.0.bn.running_mean"], ph[f"{phase}.after.clf_t.bn_mean0"], 1e-4, "clf_t BN running mean")
+    assert (not torch.equal(tr.m["clf_t"].hidden.weight.detach(), hidden0)) == ("clf_t" in tr.PHASES[phase])
+    assert (not torch.equal(tr.m["nf"].WN[0].end.weight.detach(), nf0)) == ("nf" in tr.PHASES[phase])
+
+
 def test_hipgraph_replay_matches_eager_step():
     """The captured step (one hipGraph replay) must equal the eager step from the same state, and its
     per-replay inputs (batch, CPC start indices) must be live."""
