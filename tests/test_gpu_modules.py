@@ -359,3 +359,42 @@ def test_full_size_flow_round_trip_and_bn_moments():
     y2 = layer.conv(2.5 * h)
     b = layer.conv1d.bias.view(1, -1, 1)
     close(y2 - b, 2.5 * (y - b), 1e-4, "conv linearity")
+
+
+def test_checkpoint_load_and_eval_pass_match_the_oracle(tmp_path):
+    """A checkpoint in the reference's .tar format (state_dicts captured from the reference) is loaded into fresh
+    modules; the on-device eval pass (utils.py:27-183) then predicts what the oracle's eval-mode forward predicts,
+    target side and source side (with DimensionUnification)."""
+    g = load("joint_small")
+    meta = json.loads(str(g["meta"]))
+    tup = lambda lp: [[tuple(t) for t in l] for l in lp]
+    pt, ps = str(tmp_path / "epoch_3.tar"), str(tmp_path / "epoch_3_source.tar")
+    torch.save({"epoch": 3, "feature_extraction_state_dict": tsd(sub(g, "sd0.fe_t.")),
+                "classification_state_dict": tsd(sub(g, "sd0.clf_t."))}, pt)
+    torch.save({"epoch": 3, "feature_extraction_state_dict": tsd(sub(g, "sd0.fe_s.")),
+                "source_to_target_feature_trans": tsd(sub(g, "sd0.dimunif.")),
+                "classification_state_dict": tsd(sub(g, "sd0.clf_s."))}, ps)
+    C, C_s = sum(t[1] for t in meta["lp_t"][-1]), sum(t[1] for t in meta["lp_s"][-1])
+    fe_t, clf_t = fst.OS_CNN_res(tup(meta["lp_t"])).to(DEV), fst.OS_CNN(tup(meta["lp_clf"]), meta["ncls_t"]).to(DEV)
+    fe_s, clf_s = fst.OS_CNN_res(tup(meta["lp_s"])).to(DEV), fst.OS_CNN(tup(meta["lp_clf"]), meta["ncls_s"]).to(DEV)
+    du = fst.DimensionUnification(C_s, C, meta["L_s"], meta["L_t"]).to(DEV)
+    assert fst.load_target_classification_modules(pt, fe_t, clf_t) == 3
+    assert fst.load_source_classification_modules(ps, fe_s, du, clf_s) == 3
+    for m in (fe_t, clf_t, fe_s, clf_s, du):
+        m.eval()
+    gen = torch.Generator().manual_seed(11)
+    bt = [(torch.randn(5, meta["C_in_t"], meta["L_t"], generator=gen), torch.randint(meta["ncls_t"], (5,), generator=gen)) for _ in range(3)]
+    bs = [(torch.randn(4, meta["C_in_s"], meta["L_s"], generator=gen), torch.randint(meta["ncls_s"], (4,), generator=gen)) for _ in range(3)]
+    acc_t, pred_t = fst.eval_accuracy(fe_t, clf_t, bt)
+    acc_s, pred_s = fst.eval_accuracy(fe_s, clf_s, bs, feature_trans=du)
+    P = {k: {n: torch.tensor(v) for n, v in sub(g, f"sd0.{k}.").items()} for k in ("fe_t", "clf_t", "fe_s", "dimunif", "clf_s")}
+    want_t, want_s, hit_t, hit_s = [], [], 0, 0
+    for x, y in bt:
+        logits = R.classifier(R.feature_extractor(x, P["fe_t"], tup(meta["lp_t"]), False), P["clf_t"], tup(meta["lp_clf"]), False)[0]
+        want_t.append(logits.argmax(1)); hit_t += int((logits.argmax(1) == y).sum())
+    for x, y in bs:
+        f = R.dimension_unification(R.feature_extractor(x, P["fe_s"], tup(meta["lp_s"]), False), P["dimunif"])
+        logits = R.classifier(f, P["clf_s"], tup(meta["lp_clf"]), False)[0]
+        want_s.append(logits.argmax(1)); hit_s += int((logits.argmax(1) == y).sum())
+    assert torch.equal(pred_t.cpu(), torch.cat(want_t)) and abs(acc_t - hit_t / 15) < 1e-9
+    assert torch.equal(pred_s.cpu(), torch.cat(want_s)) and abs(acc_s - hit_s / 12) < 1e-9
