@@ -427,6 +427,58 @@ def main() -> None:
         phases[f"{phase}.after.clf_t.hidden"] = M["clf_t"].state_dict()["hidden.weight"].numpy().copy()
     save("phases_small", **phases)
 
+    # ---------------------------------------------------------------- multi-source voting (multi_source_voting.py:281-424)
+    # The reference is a top-level script bound to its datasets and three checkpoints; its voting block (per-class
+    # precision weights from train-set predictions, entropy-sharpened, weight-scaled probability sum) is executed here
+    # verbatim — lines 281-424 compiled from the reference file — against stub loaders and stub "models" that return
+    # preset logits, so the golden vectors are the reference's own arithmetic.
+    from scipy.stats import entropy
+    from sklearn.metrics import accuracy_score
+    votes = {}
+    with open(os.path.join(args.ref, "multi_source_voting.py"), encoding="utf-8") as f:
+        lines = f.read().splitlines()
+    block = compile("\n" * 280 + "\n".join(lines[280:424]), "multi_source_voting.py", "exec")
+    for case, (n_class, n_train, n_test, seed, bsz) in {"a": (4, 37, 29, 1, 8), "b": (3, 50, 41, 2, 20), "c": (5, 23, 17, 3, 6)}.items():
+        rng = np.random.RandomState(seed)
+        y_train, y_test = rng.randint(n_class, size=n_train), rng.randint(n_class, size=n_test)
+        tr_logits = rng.randn(3, n_train, n_class).astype(np.float32) * 1.5
+        te_logits = rng.randn(3, n_test, n_class).astype(np.float32) * 1.5
+        for k in range(3):                                  # make the models informative, differently so
+            tr_logits[k, np.arange(n_train), y_train] += 0.8 * (k + 1)
+            te_logits[k, np.arange(n_test), y_test] += 0.8 * (k + 1)
+        if case == "c":
+            tr_logits[:, :, 4] -= 50.0                      # class 4 is never predicted by any model: 0/0 -> nan -> 0
+        table = {"train": tr_logits, "test": te_logits}
+        state = {"which": "train"}
+
+        def loader(which, n, y):
+            def it():
+                state["which"] = which
+                for i0 in range(0, n, bsz):
+                    idx = torch.arange(i0, min(n, i0 + bsz))
+                    yield idx.double(), torch.tensor(y[i0: i0 + bsz])
+            class L:                                        # enumerate(loader) restarts it, like a DataLoader
+                def __iter__(self_):
+                    return it()
+            return L()
+
+        def model(k):
+            return lambda x: (torch.tensor(table[state["which"]][k])[x.long()], None)
+
+        ns = {"torch": torch, "np": np, "entropy": entropy, "accuracy_score": accuracy_score, "target_num_class": n_class,
+              "target_train_loader": loader("train", n_train, y_train), "target_test_loader": loader("test", n_test, y_test)}
+        for k in range(3):
+            ns[f"target_feature_extraction_module{k + 1}"] = lambda x: x
+            ns[f"target_classification_module{k + 1}"] = model(k)
+        exec(block, ns)
+        votes[f"{case}.train_logits"], votes[f"{case}.test_logits"] = tr_logits, te_logits
+        votes[f"{case}.train_labels"], votes[f"{case}.test_labels"] = y_train, y_test
+        votes[f"{case}.weights"] = np.stack([ns["weight_1"], ns["weight_2"], ns["weight_3"]])
+        votes[f"{case}.scores"] = ns["result_final"]
+        votes[f"{case}.pred"] = ns["predict_list"]
+        votes[f"{case}.acc"] = np.array(float(ns["acc"]))
+    save("voting_small", **votes)
+
 
 if __name__ == "__main__":
     main()

@@ -746,3 +746,43 @@ def build_joint_step(L_t: int, C_in_t: int, L_s: int, C_in_s: int, n_class_t: in
     mods.update(init_small_heads(C, C_s, L_t, L_s, gen))
     mats = [torch.randn(C * L_t, 1024, generator=gen), torch.randn(n_class_t, 1024, generator=gen)]
     return JointStep(mods, mats, fe_t_spec, clf_spec, fe_s_spec, 3, L_t // 2, dropout_p)
+
+
+# --------------------------------------------------------------------------------------
+# multi-source voting                                   multi_source_voting.py:281-424
+# --------------------------------------------------------------------------------------
+def voting_precision_weights(train_logits: np.ndarray, train_labels: np.ndarray) -> np.ndarray:
+    """Per model k and class c: of the train samples model k predicts as c, the fraction that is c (0 if it never
+    predicts c) (:292-357); then every model's vector is divided by the mean over models, 0/0 -> nan -> 0 (:358-367)."""
+    K, N, C = train_logits.shape
+    w = np.zeros((K, C))
+    for k in range(K):
+        pred = np.argmax(train_logits[k], axis=1)
+        for c in range(C):
+            n_c = int(np.sum(pred == c))
+            w[k, c] = (np.sum((pred == c) & (pred == train_labels)) / n_c) if n_c else 0.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = np.nan_to_num(w / w.mean(axis=0))
+    return w
+
+
+def voting_scores(test_logits: np.ndarray, weights: np.ndarray) -> np.ndarray:
+    """Σ_k softmax(logits_k) · (1 + 120·exp(−H(softmax))) · 9^{w_k}   (:406-422); H = natural-log Shannon entropy."""
+    K, M, C = test_logits.shape
+    total = np.zeros((M, C), dtype=np.float32)
+    for k in range(K):
+        rows = test_logits[k].astype(np.float32).copy()
+        for i in range(M):
+            p = np.exp(rows[i]) / np.sum(np.exp(rows[i]))
+            H = -np.sum(np.where(p > 0, p * np.log(p), 0.0))
+            rows[i] = p * (1 + 120 * np.exp(-H)) * np.power(9, weights[k])
+        total += rows
+    return total
+
+
+def multi_source_vote(train_logits, train_labels, test_logits, test_labels=None):
+    w = voting_precision_weights(np.asarray(train_logits), np.asarray(train_labels))
+    scores = voting_scores(np.asarray(test_logits), w)
+    pred = np.argmax(scores, axis=1)
+    acc = None if test_labels is None else float(np.mean(pred == np.asarray(test_labels)))
+    return w, scores, pred, acc

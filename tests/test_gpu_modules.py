@@ -398,3 +398,36 @@ def test_checkpoint_load_and_eval_pass_match_the_oracle(tmp_path):
         want_s.append(logits.argmax(1)); hit_s += int((logits.argmax(1) == y).sum())
     assert torch.equal(pred_t.cpu(), torch.cat(want_t)) and abs(acc_t - hit_t / 15) < 1e-9
     assert torch.equal(pred_s.cpu(), torch.cat(want_s)) and abs(acc_s - hit_s / 12) < 1e-9
+
+
+def test_multi_source_voting_on_device_matches_the_oracle():
+    """K = 3 target-side models (the joint fixture's extractor/classifier and two perturbed copies) vote on a test
+    set: K-way eval forward + batched vote on the device == oracle eval forward + the restated voting block."""
+    g = load("joint_small")
+    meta = json.loads(str(g["meta"]))
+    tup = lambda lp: [[tuple(t) for t in l] for l in lp]
+    gen = torch.Generator().manual_seed(21)
+    models, params = [], []
+    for k in range(3):
+        Pf, Pc = tsd(sub(g, "sd0.fe_t.")), tsd(sub(g, "sd0.clf_t."))
+        if k:
+            Pc["hidden.weight"] = Pc["hidden.weight"] + 0.5 * k * torch.randn(Pc["hidden.weight"].shape, generator=gen)
+            Pc["hidden.bias"] = Pc["hidden.bias"] + 0.2 * k * torch.randn(Pc["hidden.bias"].shape, generator=gen)
+        fe, clf = fst.OS_CNN_res(tup(meta["lp_t"])).to(DEV), fst.OS_CNN(tup(meta["lp_clf"]), meta["ncls_t"]).to(DEV)
+        fe.load_state_dict(Pf); clf.load_state_dict(Pc)
+        fe.eval(); clf.eval()
+        models.append((fe, clf)); params.append((Pf, Pc))
+    mk = lambda n: [(torch.randn(6, meta["C_in_t"], meta["L_t"], generator=gen), torch.randint(meta["ncls_t"], (6,), generator=gen))
+                    for _ in range(n)]
+    train, test = mk(4), mk(3)
+    w, scores, pred, acc = fst.multi_source_voting(models, train, test)
+
+    def oracle_logits(batches):
+        out = [torch.cat([R.classifier(R.feature_extractor(x, Pf, tup(meta["lp_t"]), False), Pc, tup(meta["lp_clf"]), False)[0]
+                          for x, _ in batches]) for Pf, Pc in params]
+        return torch.stack(out).detach().numpy(), torch.cat([y for _, y in batches]).numpy()
+    (trl, try_), (tel, tey) = oracle_logits(train), oracle_logits(test)
+    w_o, scores_o, pred_o, acc_o = R.multi_source_vote(trl, try_, tel, tey)
+    np.testing.assert_allclose(w.cpu().numpy(), w_o, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(scores.cpu().numpy(), scores_o, rtol=2e-3)          # 9^w·(1+120e^-H) amplifies the 1e-4 logit tolerance
+    assert np.array_equal(pred.cpu().numpy(), pred_o) and abs(acc - acc_o) < 1e-12
