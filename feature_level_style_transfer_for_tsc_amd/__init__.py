@@ -15,6 +15,7 @@ from .widgets import (AdversarialNetworkforCDAN, DimensionUnification, FeatureDi
                       ProbTransfer, wgan_loss)
 from .step import ClassifierTrainer, JointConfig, JointTrainer, specs_for
 from .dist import GradBucket, shard_batch
+from .data import DeviceLoader, TestData, TrainData, load_ts, parse_ts
 from .voting import collect_logits, multi_source_vote, multi_source_voting, precision_weights, vote_scores
 from .checkpoint import (eval_accuracy, load_source_classification_modules, load_target_classification_modules,
                          save_source_classification_modules, save_target_classification_modules)

@@ -479,6 +479,51 @@ def main() -> None:
         votes[f"{case}.acc"] = np.array(float(ns["acc"]))
     save("voting_small", **votes)
 
+    # ---------------------------------------------------------------- dataset classes (DataSource.py:9-64)
+    # sktime is not in the image, so the .ts PARSER has no reference vectors (restated from the format's description,
+    # "parity unpinned").  The label-dictionary semantics of TrainData / TestData are pinned: the REFERENCE's classes
+    # run here on top of the build's parser (plugged in as the stub sktime's load_from_tsfile).
+    import tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from feature_level_style_transfer_for_tsc_amd.data import load_ts
+    sys.modules["sktime.datasets"].load_from_tsfile = lambda path, return_data_type="numpy3d": load_ts(path)
+    import importlib
+    import DataSource as RefDS
+    importlib.reload(RefDS)
+    head = "@problemName toy\n@timeStamps false\n@missing false\n@univariate false\n@dimensions 2\n@equalLength true\n" \
+           "@seriesLength 4\n@classLabel true walk run sit\n@data\n"
+    rng = np.random.RandomState(5)
+
+    def ts_text(labels):
+        rows = []
+        for lab in labels:
+            dims = [",".join(f"{v:.6g}" for v in rng.randn(4)) for _ in range(2)]
+            rows.append(":".join(dims + [lab]))
+        return head + "\n".join(rows) + "\n"
+
+    texts = {"target_TRAIN": ts_text(["run", "walk", "run", "sit", "walk"]), "target_TEST": ts_text(["sit", "run", "jump", "walk"]),
+             "source_TRAIN": ts_text(["sit", "sit", "hop", "run"])}
+    ds = {}
+    with tempfile.TemporaryDirectory() as d:
+        for k, t in texts.items():
+            with open(os.path.join(d, k + ".ts"), "w") as f:
+                f.write(t)
+            ds[f"text.{k}"] = np.array(t)
+        label_dict = {}
+        a = RefDS.TrainData(d, "target_TRAIN.ts", label_dict)
+        ds["dict_after_target_train"] = np.array(json.dumps(label_dict))
+        b = RefDS.TestData(d, "target_TEST.ts", label_dict)           # "jump" is unseen: reported, sample left unlabeled
+        c = RefDS.TrainData(d, "source_TRAIN.ts", label_dict)         # shared dict: only "hop" is new -> num_class == 1
+        ds["dict_final"] = np.array(json.dumps(label_dict))
+        for name, obj, xk, yk in (("target_TRAIN", a, "train_x", "train_y"), ("target_TEST", b, "test_x", "test_y"),
+                                  ("source_TRAIN", c, "train_x", "train_y")):
+            ds[f"{name}.x"], ds[f"{name}.y"] = getattr(obj, xk).numpy(), getattr(obj, yk).numpy()
+            ds[f"{name}.meta"] = np.array([obj.len, obj.in_channel, obj.time_length, obj.num_class])
+            ds[f"{name}.item1_x"], ds[f"{name}.item1_y"] = obj[1][0].numpy(), np.array(int(obj[1][1]))
+    save("datasource_small", **ds)
+
 
 if __name__ == "__main__":
     main()

@@ -431,3 +431,22 @@ def test_multi_source_voting_on_device_matches_the_oracle():
     np.testing.assert_allclose(w.cpu().numpy(), w_o, rtol=1e-9, atol=0)
     np.testing.assert_allclose(scores.cpu().numpy(), scores_o, rtol=2e-3)          # 9^w·(1+120e^-H) amplifies the 1e-4 logit tolerance
     assert np.array_equal(pred.cpu().numpy(), pred_o) and abs(acc - acc_o) < 1e-12
+
+
+def test_device_loader_pinned_async_copies():
+    """The H2D side of the input pipeline: float32 cast, pinned staging, one batch ahead on a side stream."""
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 3, 64, generator=gen, dtype=torch.float64)
+    y = torch.randint(5, (37,), generator=gen)
+    ld = fst.DeviceLoader(x, y, 8, DEV)
+    xs, ys = [], []
+    for xb, yb in ld:
+        assert xb.is_cuda and xb.dtype == torch.float32 and yb.is_cuda
+        xs.append((xb * 2).cpu() / 2); ys.append(yb.cpu())            # consume on the current stream
+    assert torch.equal(torch.cat(xs), x.float()) and torch.equal(torch.cat(ys), y) and len(ld) == 5
+    sh = fst.DeviceLoader(x, y, 8, DEV, generator=torch.Generator().manual_seed(1), drop_last=True)
+    n = 0
+    for xb, yb in sh:                                                 # shuffled: every batch is a gather of the source rows
+        assert xb.shape == (8, 3, 64) and yb.shape == (8,)
+        n += 8
+    assert n == 32 and len(sh) == 4
