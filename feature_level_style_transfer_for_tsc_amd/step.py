@@ -331,9 +331,12 @@ class JointTrainer:
             # GradNorm (:682-690): per-loss gradient norms over the 12 shared tensors
             sh_t = list(self.m["fe_t"].return_last_layer().parameters())
             sh_s = list(self.m["fe_s"].return_last_layer().parameters())
+            # Differentiate the loss tensors themselves, not lt[i] / ls[i]: a select of the stacked vector sends a ZERO
+            # cotangent down every other loss's graph (autograd does not prune zeros), i.e. 8 WaveGlow backward
+            # traversals per step where 4 carry anything (ce_t / ce_s never touch the flow).  Same values, half the work.
             with ops.partial_backward():
-                g_t = [torch.autograd.grad(lt[i], sh_t, retain_graph=True) for i in range(2)]
-                g_s = [torch.autograd.grad(ls[i], sh_s, retain_graph=(i < 2)) for i in range(3)]
+                g_t = [torch.autograd.grad(L[k], sh_t, retain_graph=True) for k in ("nf_t", "ce_t")]
+                g_s = [torch.autograd.grad(L[k], sh_s, retain_graph=(k != "ce_s2t2s")) for k in ("nf_s", "ce_s", "ce_s2t2s")]
             if _dist.global_batch_active():
                 # mode B: the norms are those of the GLOBAL per-loss gradients (mean over ranks), not means of norms
                 flat = torch.cat([g.reshape(-1) for gs in g_t + g_s for g in gs])
