@@ -265,11 +265,18 @@ def row_sum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 
 def wgrad_ksplit(B: int, L: int, n_wg_per_slice: int) -> int:
-    """Split (b, t) so that the launch has ≈ 2 workgroups per CU (two fit): every extra slice adds one
-    fp32-atomic pass over the packed gradient, which at ~1.3 TB/s is not free."""
+    """Split of (b, t) over workgroups.  All workgroups of the launch must be co-resident (2 per CU x 256 CUs): one
+    more than that is a whole second round at the length of the first.  Workgroup id = slice + ksplit * item_group,
+    and ids round-robin over the 8 XCDs, so with a multiple of 8 the item-groups that re-read one slice of dy sit on
+    one XCD and share its L2.  Every slice adds an fp32-atomic pass over the packed gradient, so no more than fit."""
     tiles = B * ((L + 31) // 32)
-    want = max(1, (512 + n_wg_per_slice - 1) // n_wg_per_slice)
-    return max(1, min(tiles, want))
+    # a single item group (K <= 128 packed rows) is bound by its atomics — every slice adds a full pass over the
+    # packed gradient — and measures best at 1.5 workgroups per CU (118 -> 93 us on the 120 -> 240 1x1 layers)
+    target = 384 if n_wg_per_slice == 1 else 512
+    k = max(1, target // max(1, n_wg_per_slice))
+    if k >= 16:
+        k -= k % 8
+    return max(1, min(tiles, k))
 
 
 # --------------------------------------------------------------------------------------------------
