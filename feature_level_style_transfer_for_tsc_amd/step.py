@@ -26,6 +26,7 @@ from .cdan import CDAN, RandomLayer
 from .cpc import CPC
 from . import dist as _dist
 from .dist import GradBucket
+from .optim import SharedStepAdam
 from .os_cnn import OS_CNN, OS_CNN_res, build_layer_with_layer_parameter
 from .structure import generate_layer_parameter_list, layer_parameter_list_input_change, out_channels
 from .waveglow import WaveGlow, WaveGlowLoss
@@ -138,7 +139,9 @@ class JointTrainer:
         self.nf_loss = WaveGlowLoss()
         # capturable=True keeps the optimiser step counters on the device (needed under hipGraph capture)
         self.opts = {k: torch.optim.RMSprop(self.m[k].parameters(), lr=lr, capturable=True) for k, lr in self.LRS.items()}
-        self.opt_cpc = torch.optim.Adam(self.m["cpc"].parameters(), lr=0.002, capturable=True)
+        # CPC = 516 small tensors: torch's capturable Adam spends ~4 k tiny kernels per step on per-parameter step
+        # counters; same update with one shared device counter (optim.SharedStepAdam)
+        self.opt_cpc = SharedStepAdam(self.m["cpc"].parameters(), lr=0.002)
         self.w_t = nn.Parameter(torch.tensor([2.0, 5.0], device=device))         # :501-505
         self.w_s = nn.Parameter(torch.tensor([2.0, 2.0, 4.0], device=device))
         self.opt_w_t = torch.optim.Adam([self.w_t], lr=0.0002, capturable=True)
