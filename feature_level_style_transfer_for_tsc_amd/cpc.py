@@ -24,6 +24,30 @@ class CPC(nn.Module):
         self.timestep = timestep
         self.Wk = nn.ModuleList([nn.Linear(self.hidden_dim, num_channels) for _ in range(self.timestep)])
         self.lsoftmax = nn.LogSoftmax(dim=-1)
+        self._stack_cache = None
+
+    def _stacked(self):
+        """The T predictors as one [T, C, H] / [T, C] pair.  Inside ``shared_stack()`` the pair is built once and
+        reused by every call (the joint step runs CPC twice): the gradient then reaches the 2·T separate parameters
+        through ONE unbind instead of being accumulated tensor by tensor per call."""
+        if self._stack_cache is not None and self._stack_cache[0] is not None:
+            return self._stack_cache
+        pair = (torch.stack([l.weight for l in self.Wk]), torch.stack([l.bias for l in self.Wk]))
+        if self._stack_cache is not None:
+            self._stack_cache = pair
+        return pair
+
+    def shared_stack(self):
+        mod = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev, mod._stack_cache = mod._stack_cache, (None, None)
+
+            def __exit__(self_, *exc):
+                mod._stack_cache = self_.prev
+                return False
+        return _Ctx()
 
     def forward(self, features: torch.Tensor, t_samples=None) -> torch.Tensor:
         """``t_samples`` pins the random start (quirk Q6); by default it is drawn from the global CPU RNG
@@ -44,8 +68,7 @@ class CPC(nn.Module):
             output, _ = self.gru(z[:, : t_samples + 1, :].contiguous())
             c_t = output[:, t_samples, :].reshape(B, self.hidden_dim)
             t0 = t_samples + 1
-        W = torch.stack([l.weight for l in self.Wk])                          # [T, C, H]
-        b = torch.stack([l.bias for l in self.Wk])                            # [T, C]
+        W, b = self._stacked()
         pred = torch.baddbmm(b.unsqueeze(1), c_t.unsqueeze(0).expand(T, B, -1), W.transpose(1, 2))   # [T, B, C]
         # global-batch data parallelism: the negatives of a row are the predictions of EVERY rank's samples
         return ops.CPCNceFn.apply(features, _dist.gather_cat(pred, 1), t0, T, _dist.rank() * B)

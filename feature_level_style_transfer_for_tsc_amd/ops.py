@@ -480,8 +480,10 @@ class ConvSpec:
         n_wg = max(1, len(plan.items()) // 4)
         da = conv_wgrad(plan, x0, x1, dy, dy2, self.M if msplit is None else msplit, B, L, self.M,
                         wgrad_ksplit(B, L, n_wg))
-        dw0 = torch.zeros(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
-        dw1 = torch.zeros(self.M, self.C1, 1, device=x0.device, dtype=torch.float32) if self.C1 else None
+        # a dense plan (every tap of every row) makes unpack write every element: no zero fill needed
+        alloc = torch.empty if (self.dense_dw or self.row_live is None) else torch.zeros
+        dw0 = alloc(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
+        dw1 = alloc(self.M, self.C1, 1, device=x0.device, dtype=torch.float32) if self.C1 else None
         unpack_weights(plan, self.M, da, dw0, self.s_w0(), dw1, self.s_w1())
         return dw0, dw1
 

@@ -287,7 +287,7 @@ class JointTrainer:
     def phase_step(self, phase: str, x_t, y_t, x_s, y_s, t_samples=(None, None)):
         """One batch of a pre-training phase: forward, backward, the phase's optimisers, zero_grad (eager)."""
         with _dist.global_batch(self.bucket if self.sync == "global" else None):
-            with ops.pack_cache(), self.m["nf"].shared_fold():
+            with ops.pack_cache(), self.m["nf"].shared_fold(), self.m["cpc"].shared_stack():
                 total, L = self.phase_losses(phase, x_t, y_t, x_s, y_s, t_samples)
                 for o in self.opts.values():
                     o.zero_grad(set_to_none=True)
@@ -319,7 +319,7 @@ class JointTrainer:
         return self._step_part_b(mid)
 
     def _step_part_a(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
-        with ops.pack_cache(), self.m["nf"].shared_fold():
+        with ops.pack_cache(), self.m["nf"].shared_fold(), self.m["cpc"].shared_stack():
             L, aux = self.forward_losses(x_t, y_t, x_s, y_s, t_samples, noise_ratios)
             lt = torch.stack([L["nf_t"], L["ce_t"]])
             ls = torch.stack([L["nf_s"], L["ce_s"], L["ce_s2t2s"]])
