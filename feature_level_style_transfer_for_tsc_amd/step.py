@@ -55,6 +55,11 @@ def loss_coefficients(epoch: int) -> Tuple[float, float, float, float]:
     return 1.5, 1.5, 2.5, 2.5
 
 
+# hipGraph capture must not be invalidated by other threads' HIP calls: with an RCCL communicator alive, PyTorch's
+# watchdog thread polls events while the step is being captured ("global" mode would then abort the capture).
+_CAPTURE_MODE = "thread_local"
+
+
 class ClassifierTrainer:
     def __init__(self, length: int, in_channel: int, n_class: int, device, bucket: Optional[GradBucket] = None,
                  sync: str = "ddp"):
@@ -427,15 +432,15 @@ class JointTrainer:
         self._replay_inputs(x_t, y_t, x_s, y_s, (0, 0))
         if self.bucket is None:
             self._graphs = [torch.cuda.CUDAGraph()]
-            with torch.cuda.graph(self._graphs[0]):
+            with torch.cuda.graph(self._graphs[0], capture_error_mode=_CAPTURE_MODE):
                 self._g_out = self._graph_body()
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with torch.cuda.graph(ga, capture_error_mode=_CAPTURE_MODE):
                 self._g_mid = self._graph_part_a()
             pool = ga.pool()
             self._reduce(self._g_mid)                                         # eager; also fixes the bucket's buffer
-            with torch.cuda.graph(gb, pool=pool):
+            with torch.cuda.graph(gb, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 self._g_out = self._step_part_b(self._g_mid)
             self._graphs = [ga, gb]
         return self
