@@ -79,6 +79,55 @@ def classifier_step_rate(fst, device, B: int, L: int, steps: int = 30, warmup: i
             "workload": f"S1 classifier-only step (OS_CNN_res + OS_CNN + CE + RMSprop), univariate L={L}, batch {B}, eager"}
 
 
+def _timed(fn, reps: int = 10, warm: int = 2) -> float:
+    """ms per call, HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def north_star_extras(fst, ops, trainer, x_t, B: int, L: int):
+    """The three figures BASELINE.json's north_star asks for besides the step rate: the omni-scale Conv1d
+    sweep as algorithmic HBM GB/s (input once, features once) next to its FLOP rate, the CPC cross-Gram ("Gram GEMM")
+    and the CDAN random-layer GEMM against their ceilings.  Forward kernels only, HIP-event timed, no autograd."""
+    out = {}
+    with torch.no_grad():
+        fe = trainer.m["fe_t"]
+        C_in, C = x_t.size(1), 50
+        ms = _timed(lambda: fe(x_t))
+        macs = 964 * C_in + 216900 + 16875 + 50 * C_in                       # live MACs per timestep (SURVEY §8d)
+        out["omni_scale_fe_forward"] = {
+            "ms": ms, "algorithmic_GBps": 4.0 * (C_in + C) * B * L / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
+            "TFLOPps": 2.0 * macs * B * L / (ms * 1e-3) / 1e12,
+            "note": "OS_CNN_res forward incl. train-mode BatchNorm passes; layer 1 (216 900 live MACs/timestep) runs on "
+                    "conv_win_bf3_kernel — see roofline.kernels for its own rate; the block is compute-bound, the GB/s "
+                    "figure is input + features once"}
+        feat = torch.randn(B, C, L, device=x_t.device)
+        T = L // 2
+        pred = torch.randn(T, B, C, device=x_t.device) * 0.3
+        ms = _timed(lambda: ops.CPCNceFn.apply(feat, pred, 7, T))
+        out["cpc_cross_gram"] = {"ms": ms, "TFLOPps": 2.0 * T * B * B * C / (ms * 1e-3) / 1e12, "peak_TFLOPps": 157.3,
+                                 "note": "all T cross-Grams enc_i·pred_iT (K = C = 50) on v_mfma_f32_32x32x2_f32 (exact fp32), "
+                                         "log-softmax + diagonal fused on the accumulators; priced against the f32 MFMA peak"}
+        rl = trainer.random_layer
+        xf = torch.randn(B, C * L, device=x_t.device)
+        R0 = rl.random_matrix[0]
+        ms = _timed(lambda: ops._fixed_matmul(xf, R0, B, C * L, R0.size(1)))
+        out["cdan_random_layer_gemm"] = {
+            "ms": ms, "TFLOPps": 2.0 * B * C * L * R0.size(1) / (ms * 1e-3) / 1e12,
+            "algorithmic_GBps": 4.0 * (R0.numel() + xf.numel() + B * R0.size(1)) / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
+            "note": "256 x 25600 x 1024 on the conv engine (split-bf16 MFMA, K split with fp32 atomics); the 105 MB fixed "
+                    "matrix is read once: HBM-bound at small B"}
+    return out
+
+
 def kernel_peak(key: str) -> float:
     """Dense MFMA peak (algorithmic TFLOP/s) of the instruction a conv-engine kernel is built on."""
     bf3 = "bf3" in key or (key.startswith("conv_wgrad_kernel") and key.rstrip(">").endswith("true"))
@@ -223,6 +272,7 @@ def main() -> None:
                 "roofline": roofline}
         if world == 1:
             line["s1_classifier_step"] = classifier_step_rate(fst, device, args.batch, args.length)
+            line["north_star_extras"] = north_star_extras(fst, ops, trainer, x_t, args.batch, args.length)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.length, args.cpu_pairs, args.cpu_steps)
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
