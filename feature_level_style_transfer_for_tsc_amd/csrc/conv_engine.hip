@@ -1,19 +1,25 @@
 // Conv engine for gfx950: every convolution on the train-step hot path (omni-scale prime-kernel
 // layers, 1x1 shortcuts, WaveGlow dilated/1x1 convs, their data gradients and weight gradients) is
-// one of the two f32-MFMA kernels in this file, driven by a small "plan" table (plan.py).
+// one of the kernels in this file, driven by a small "plan" table (plan.py):
 //
-//   conv_gemm_kernel   y[b,m,t]  = Σ_k A[m,k] · xcol[b,k,t]          (forward and data-gradient)
-//   conv_wgrad_kernel  dA[m,k]  += Σ_{b,t} dy[b,m,t] · xcol[b,k,t]   (weight gradient, split over b,t)
+//   y[b,m,t]  = Σ_k A[m,k] · xcol[b,k,t]         forward and data gradient
+//     conv_gemm_bf3_kernel   single-tap 16-channel stages through a 3-slot LDS-DMA ring          (split-bf16 MFMA)
+//     conv_win_bf3_kernel    omni-scale layers: one [time][16 ch] window per chunk, tap = row     (split-bf16 MFMA)
+//     conv_gemm_pipe_kernel  the f32 form of the stages (L % 4 != 0, FST_MATH=f32)                (f32 MFMA)
+//     conv_gemm_kernel       the f32 form of the window (C_in < 8, FST_MATH=f32)                  (f32 MFMA)
+//   dA[m,k] += Σ_{b,t} dy[b,m,t] · xcol[b,k,t]   weight gradient, split over (b,t), fp32 atomics
+//     conv_wgrad_kernel<..., BF3>                                                        (split-bf16 or f32 MFMA)
 //
-// Mapping to v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD — MI355X_MICROARCH "Matrix cores"):
-//   forward : A-operand = packed weights (lane ↔ output row, k ↔ channel parity), read from L2 as one
-//             coalesced 256-B record per k-step; B-operand = the input window staged ONCE in LDS as
-//             [channel][time], lane ↔ time so consecutive lanes hit consecutive banks; a tap is just
-//             an LDS column offset, so every kernel size of an omni-scale layer is produced from the
-//             same staged window.
-//   wgrad   : time is the MFMA k dimension; both operands come out of LDS transposed (odd row
-//             strides → conflict-free), accumulators are written with fp32 atomics whose lanes cover
-//             two 128-B segments (the full-rate shape, MI355X_MICROARCH "Global float atomics").
+// Two arithmetics.  f32: v_mfma_f32_32x32x2_f32 (exact fp32 chain, 64 FLOP/clk/SIMD).  Split-bf16 ("bf16x3"):
+// every fp32 operand v = hi + lo with hi = bf16(v), lo = bf16(v - hi) (round to nearest), a product formed as
+// hi·hi + hi·lo + lo·hi by three v_mfma_f32_32x32x16_bf16 with fp32 accumulation — relative error of a product
+// <= 3·2^-18 (measured 5e-6 of the output scale) at a third of the 2.5 PFLOP/s bf16 peak instead of 157 TFLOP/s.
+// Weights are split when packed (fst_pack_weights_bf16x3), activations in registers on their way to the MFMA.
+//
+// Shared ideas: lane <-> output row / time sample so LDS reads are conflict-free; a tap is an LDS offset; per
+// 32-row block only live taps are multiplied; the plan table is a separate __restrict__ kernel argument so it is
+// read with scalar loads; one branch-free epilogue (bias / residual / accumulate / split / atomics) with 16-byte
+// stores through a wave-private LDS transpose.
 #include "fst_common.h"
 #include <type_traits>
 
