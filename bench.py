@@ -155,6 +155,11 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # Rehearsal on a one-GPU box only (never set by the driver): FST_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # FST_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device), so the N>1 code path — two captured
+    # graphs with the eager all-reduce between them, barrier + MAX timing — can be exercised without a multi-GPU node.
+    if os.environ.get("FST_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -165,7 +170,11 @@ def main() -> None:
     bucket = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("FST_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         dist.barrier()
     import feature_level_style_transfer_for_tsc_amd as fst
     from feature_level_style_transfer_for_tsc_amd import ops
@@ -219,11 +228,11 @@ def main() -> None:
     # (same kernels, same shapes as the timed steps; a captured graph cannot carry timing events)
     timer = ops.KernelTimer()
     n_timer_steps = 1
-    if rank == 0:
-        ops.KERNEL_TIMER = timer
-        trainer.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=draw_t())
-        torch.cuda.synchronize()
-        ops.KERNEL_TIMER = None
+    # every rank runs the step (it contains the gradient all-reduce); only rank 0 records the kernel timings
+    ops.KERNEL_TIMER = timer if rank == 0 else None
+    trainer.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=draw_t())
+    torch.cuda.synchronize()
+    ops.KERNEL_TIMER = None
     ms_per_step = 1e3 * dt / args.steps
     value = world * args.batch * args.steps / dt
 
@@ -264,7 +273,7 @@ def main() -> None:
                 "config": {"workload": "configs[1]: full joint step (OS_CNN_res x2 + OS_CNN x3 + WaveGlow(3,50,120) fwd x2 + infer "
                                        "+ CPC x2 + CDAN + GradNorm + RMSprop/Adam), univariate L=%d, %d pairs/GPU" % (args.length, args.batch),
                            "global_batch": world * args.batch, "seq_len": args.length, "parallelism": f"dp{world}"},
-                "mode": mode,
+                "mode": mode, "dist_backend": (os.environ.get("FST_BENCH_BACKEND", "nccl") if world > 1 else None),
                 "arithmetic": ("fp32 storage; GEMM products as hi*hi + hi*lo + lo*hi of round-to-nearest bf16 halves on "
                                "v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error ~5e-6 of the output scale); the "
                                "omni-scale window kernel and everything pointwise in f32") if ops.MATH == "bf16x3" else "f32 MFMA",
