@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
   const float gs = p.gout[0] / ((float)B * (float)p.T);   // d nce / d total = (softmax − I)/(B·T)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int jcol = threadIdx.x;                           // this thread's dpred column (Bc ≤ 256)
+  // dpred is accumulated in registers, CMAX channels of one column per thread; wider features take several passes
+  // over the row blocks (the dt tile is re-formed per pass, denc is written in the first one)
+  for (int c0 = 0; c0 < C; c0 += CMAX) {
   float dp[CMAX];
 #pragma unroll
   for (int c = 0; c < CMAX; ++c) dp[c] = 0.f;
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
     }
     __syncthreads();
     // denc[b][c] = Σ_j dt[b][j]·pred[j][c]
+    if (c0 == 0)
     for (int o = threadIdx.x; o < CPC_ROWS * C; o += 256) {
       const int r = o / C, c = o - r * C;
       const int b = r0 + r;
@@ -211,16 +215,17 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
         const float* er = encl + r * C;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
-          if (c < C) dp[c] = fmaf(d, er[c], dp[c]);
+          if (c0 + c < C) dp[c] = fmaf(d, er[c0 + c], dp[c]);
       }
     }
   }
   if (jcol < Bc) {
-    float* out = p.dpred + ((long long)i * Bc + jcol) * C;
+    float* out = p.dpred + ((long long)i * Bc + jcol) * C + c0;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
-      if (c < C) out[c] = dp[c];
+      if (c0 + c < C) out[c] = dp[c];
   }
+  }   // channel chunks
 }
 
 static int cpc_check(const CpcParams& p, size_t lds_bytes, const char* who) {
@@ -265,7 +270,6 @@ extern "C" int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64
   if (int rc = cpc_check(p, lds_bytes, "fst_cpc_nce_bwd")) return rc;
   FST_REQUIRE(gout && denc && dpred, "fst_cpc_nce_bwd: null gradient buffer");
   FST_REQUIRE(Bc <= 256, "fst_cpc_nce_bwd: %d > 256 negatives (columns) not supported yet", Bc);
-  FST_REQUIRE(C <= 128, "fst_cpc_nce_bwd: C=%d > 128 not supported yet", C);
   void (*fn)(CpcParams) = C <= 32 ? cpc_bwd_kernel<32> : (C <= 64 ? cpc_bwd_kernel<64> : cpc_bwd_kernel<128>);
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)fn, "fst_cpc_nce_bwd")) return rc;

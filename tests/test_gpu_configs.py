@@ -153,3 +153,27 @@ def test_config4_joint_forward_losses_L1024():
     for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s"):
         a, b = float(Lg[k]), float(Lo[k])
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+
+
+def test_config0_shape_full_joint_step():
+    """The whole joint step at the GunPoint-like shape (L = 150 -> 13 primes, feature width C = 130 > 128 channels,
+    L % 4 != 0 so the pipelined convs take the f32 kernels): the nine losses against the oracle, then one optimisation
+    step (GradNorm, all optimisers) runs through."""
+    js = R.build_joint_step(150, 1, 150, 1, 2, 2, seed=150, dropout_p=0.0, zero_end=False)
+    cfg = fst.JointConfig(L_t=150, C_in_t=1, L_s=150, C_in_s=1, n_class_t=2, n_class_s=2, dropout_p=0.0)
+    tr = fst.JointTrainer(cfg, DEV)
+    tr.load_params({k: {n: t.detach() for n, t in v.items()} for k, v in js.m.items()}, js.mats)
+    gen = torch.Generator().manual_seed(3)
+    mk = lambda: (torch.randn(6, 1, 150, generator=gen), torch.randint(2, (6,), generator=gen))
+    (x_t, y_t), (x_s, y_s) = mk(), mk()
+    Lo, _ = js.forward_losses(x_t, y_t, x_s, y_s, (20, 9))
+    args = (x_t.to(DEV), y_t.to(DEV), x_s.to(DEV), y_s.to(DEV))
+    snap = tr.snapshot()
+    Lg, _ = tr.forward_losses(*args, (20, 9), tr.m["noise"].advance(6, 6))
+    for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s"):
+        a, b = float(Lg[k]), float(Lo[k])
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+    tr.restore(snap)
+    rep = tr.step(*args, epoch=0, t_samples=(20, 9))
+    assert all(torch.isfinite(rep[k]).all() for k in ("nf_t", "ce_t", "sl_t", "cdan", "w_t", "w_s"))
+    assert abs(float(rep["w_t"].sum()) - 7.0) < 1e-3 and abs(float(rep["w_s"].sum()) - 8.0) < 1e-3   # renormalised (:756-761)

@@ -180,3 +180,24 @@ def test_global_batch_mode_reproduces_the_single_process_step():
             by_mod[mod][1] = max(by_mod[mod][1], float(np.abs(ref).max()))
         for mod, (err, scale) in by_mod.items():
             assert err <= 2e-3 * max(scale, 1e-6), f"rank {rank}: gradients of {mod} differ: {err:.3e} vs scale {scale:.3e}"
+
+
+def test_bench_data_parallel_path_rehearsal():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), rehearsed on
+    this one-GPU box: both ranks on cuda:0, gloo instead of RCCL.  Guards the N>1 bench path — two captured graphs with
+    the eager all-reduce between them, barrier + MAX timing, the per-kernel timing step on every rank — and its JSON."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FST_BENCH_ONE_DEVICE="1", FST_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+           "--length", "128"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                            # rank 0 prints exactly one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 32
+    assert d["mode"] == "graph" and d["dist_backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1 and "roofline" in d and "cpu_baseline" not in d

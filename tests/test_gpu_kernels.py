@@ -244,7 +244,8 @@ def test_gate_and_coupling():
     assert_close(xid, xi, 1e-5, "inv fwd"); assert_close(xd.grad, x.grad, 1e-5, "inv dx"); assert_close(o2d.grad, o2.grad, 1e-5, "inv do")
 
 
-@pytest.mark.parametrize("B,C,L,T,t0", [(4, 6, 20, 10, 3), (37, 50, 128, 64, 9), (256, 50, 512, 256, 101)])
+@pytest.mark.parametrize("B,C,L,T,t0", [(4, 6, 20, 10, 3), (37, 50, 128, 64, 9), (256, 50, 512, 256, 101),
+                                        (50, 130, 150, 75, 11), (16, 144, 128, 64, 5)])        # feature widths > 128 (L = 150, 128)
 def test_cpc_nce(B, C, L, T, t0):
     g = torch.Generator().manual_seed(B + C)
     feat = torch.randn(B, C, L, generator=g, dtype=torch.float64, requires_grad=True)
