@@ -177,3 +177,27 @@ def test_config0_shape_full_joint_step():
     rep = tr.step(*args, epoch=0, t_samples=(20, 9))
     assert all(torch.isfinite(rep[k]).all() for k in ("nf_t", "ce_t", "sl_t", "cdan", "w_t", "w_s"))
     assert abs(float(rep["w_t"].sum()) - 7.0) < 1e-3 and abs(float(rep["w_s"].sum()) - 8.0) < 1e-3   # renormalised (:756-761)
+
+
+def test_config3_shape_full_joint_step():
+    """The whole joint step at config 3's geometry (9 channels, L = 5000: a 1 GB CDAN random matrix, T = 2500 CPC steps,
+    39 full 128-sample tiles + 8): the nine losses against the oracle, then one optimisation step runs through."""
+    L, C_in, B = 5000, 9, 2
+    js = R.build_joint_step(L, C_in, L, C_in, 6, 6, seed=5, dropout_p=0.0, zero_end=False)
+    cfg = fst.JointConfig(L_t=L, C_in_t=C_in, L_s=L, C_in_s=C_in, n_class_t=6, n_class_s=6, dropout_p=0.0)
+    tr = fst.JointTrainer(cfg, DEV)
+    tr.load_params({k: {n: t.detach() for n, t in v.items()} for k, v in js.m.items()}, js.mats)
+    gen = torch.Generator().manual_seed(1)
+    mk = lambda: (torch.randn(B, C_in, L, generator=gen), torch.randint(6, (B,), generator=gen))
+    (x_t, y_t), (x_s, y_s) = mk(), mk()
+    Lo, _ = js.forward_losses(x_t, y_t, x_s, y_s, (100, 37))
+    args = (x_t.to(DEV), y_t.to(DEV), x_s.to(DEV), y_s.to(DEV))
+    snap = tr.snapshot()
+    Lg, _ = tr.forward_losses(*args, (100, 37), tr.m["noise"].advance(B, B))
+    for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s"):
+        a, b = float(Lg[k]), float(Lo[k])
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+    tr.restore(snap)
+    rep = tr.step(*args, epoch=0, t_samples=(100, 37))
+    assert all(torch.isfinite(rep[k]).all() for k in ("nf_t", "ce_t", "sl_t", "cdan", "w_t", "w_s"))
+    assert abs(float(rep["w_t"].sum()) - 7.0) < 1e-3 and abs(float(rep["w_s"].sum()) - 8.0) < 1e-3
