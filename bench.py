@@ -266,7 +266,12 @@ def main() -> None:
                                     "tflops": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12, 2),
                                     "frac_of_mfma_peak": round(v["flops"] / (v["total_ms"] * 1e-3) / 1e12 / kernel_peak(k), 3)}
                                 for k, v in ks.items()}}
-        line = {"metric": "train-step samples/sec (univariate TS, len=512, batch=256)", "value": value, "unit": "samples/s",
+        metric = "train-step samples/sec (univariate TS, len=512, batch=256) at 1/2/4/8 MI355X"
+        try:                                                                   # BASELINE.json's own string when present
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] or metric
+        except (OSError, KeyError, ValueError):
+            pass
+        line = {"metric": metric, "value": value, "unit": "samples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16x3" if ops.MATH == "bf16x3" else "f32", "data": "synthetic",
