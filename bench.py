@@ -55,7 +55,14 @@ def cpu_baseline(L: int, pairs: int, steps: int):
     for _ in range(steps):
         js.step(x_t, y_t, x_s, y_s, epoch=0)
     dt = (time.perf_counter() - t0) / steps
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?")
+    except OSError:
+        pass
     return {"value": pairs / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": model, "host_logical_cpus": os.cpu_count(), "cpus_in_affinity": len(os.sched_getaffinity(0)),
             "sample": f"joint step S2 (L={L}, C_in=1), {pairs} pairs/step, {steps} timed steps after 1 warm-up "
                       f"({steps * dt:.0f} s of CPU work), autograd anomaly mode off, {dt:.2f} s/step"}
 
