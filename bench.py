@@ -74,16 +74,25 @@ def classifier_step_rate(fst, device, B: int, L: int, steps: int = 30, warmup: i
     x, y = synthetic_batch(B, 1, L, 4, device, 3000)
     for _ in range(warmup):
         tr.step(x, y)
+    mode = "graph"
+    try:
+        tr.capture(x, y)
+        run = lambda: tr.replay(x, y)
+    except Exception as e:                                                    # noqa: BLE001 — report, then time eagerly
+        print(f"[bench] S1 capture failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr, flush=True)
+        mode, run = "eager", (lambda: tr.step(x, y))
+        torch.cuda.synchronize()
+    run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(steps):
-        tr.step(x, y)
+        run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return {"value": 1e3 * B / ms, "unit": "samples/s", "ms_per_step": ms, "steps": steps,
-            "workload": f"S1 classifier-only step (OS_CNN_res + OS_CNN + CE + RMSprop), univariate L={L}, batch {B}, eager"}
+    return {"value": 1e3 * B / ms, "unit": "samples/s", "ms_per_step": ms, "steps": steps, "mode": mode,
+            "workload": f"S1 classifier-only step (OS_CNN_res + OS_CNN + CE + RMSprop), univariate L={L}, batch {B}"}
 
 
 def _timed(fn, reps: int = 10, warm: int = 2) -> float:

@@ -67,24 +67,51 @@ class ClassifierTrainer:
         fe_spec, clf_spec = specs_for(length, in_channel)
         self.fe = OS_CNN_res(fe_spec).to(device)
         self.clf = OS_CNN(clf_spec, n_class).to(device)
-        self.opt_fe = torch.optim.RMSprop(self.fe.parameters(), lr=0.001)
-        self.opt_clf = torch.optim.RMSprop(self.clf.parameters(), lr=0.003)
+        # capturable: the optimisers' step counters live on the device, so the step can be captured into a hipGraph
+        self.opt_fe = torch.optim.RMSprop(self.fe.parameters(), lr=0.001, capturable=True)
+        self.opt_clf = torch.optim.RMSprop(self.clf.parameters(), lr=0.003, capturable=True)
         self.bucket = bucket
         self.fe.train(); self.clf.train()
+        self._graph = None
 
     def parameters(self) -> List[nn.Parameter]:
         return list(self.fe.parameters()) + list(self.clf.parameters())
 
     def step(self, x: torch.Tensor, y: torch.Tensor):
         with _dist.global_batch(self.bucket if self.sync == "global" else None):
-            logits, _ = self.clf(self.fe(x))
-            loss = F.cross_entropy(logits, y)
-            loss.backward()
+            with ops.pack_cache():
+                logits, _ = self.clf(self.fe(x))
+                loss = F.cross_entropy(logits, y)
+                loss.backward()
         if self.bucket is not None:
             self.bucket.all_reduce(self.parameters())
         self.opt_fe.step(); self.opt_clf.step()
         self.opt_fe.zero_grad(set_to_none=True); self.opt_clf.zero_grad(set_to_none=True)
         return loss.detach(), logits.detach()
+
+    # ---- single GPU: the whole step as one hipGraph (the eager step is launch-bound: ~300 launches for ~2 ms of GPU work)
+    def capture(self, x: torch.Tensor, y: torch.Tensor, warmup: int = 3):
+        if self.bucket is not None:
+            raise RuntimeError("ClassifierTrainer.capture(): single-GPU only (the DP step has an eager all-reduce)")
+        self._g_x, self._g_y = x.clone(), y.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(self._g_x, self._g_y)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, capture_error_mode=_CAPTURE_MODE):
+            self._g_out = self.step(self._g_x, self._g_y)
+
+    def replay(self, x: torch.Tensor, y: torch.Tensor):
+        """One captured step on a new batch of the captured shape; returns (loss, logits) in static buffers."""
+        if self._graph is None:
+            raise RuntimeError("call capture() first")
+        self._g_x.copy_(x); self._g_y.copy_(y)
+        self._graph.replay()
+        return self._g_out
 
 
 @dataclass

@@ -201,3 +201,39 @@ def test_config3_shape_full_joint_step():
     rep = tr.step(*args, epoch=0, t_samples=(100, 37))
     assert all(torch.isfinite(rep[k]).all() for k in ("nf_t", "ce_t", "sl_t", "cdan", "w_t", "w_s"))
     assert abs(float(rep["w_t"].sum()) - 7.0) < 1e-3 and abs(float(rep["w_s"].sum()) - 8.0) < 1e-3
+
+
+def test_classifier_step_graph_replay_matches_eager():
+    """The captured S1 step (one hipGraph replay) equals the eager step from the same state, on a new batch."""
+    gen = torch.Generator().manual_seed(7)
+    fe_spec, clf_spec = R.train_specs(64, 1)
+    Pf, Pc = R.init_feature_extractor(fe_spec, gen), R.init_classifier(clf_spec, 3, gen)
+    mk = lambda: (torch.randn(8, 1, 64, generator=gen).to(DEV), torch.randint(3, (8,), generator=gen).to(DEV))
+    (x0, y0), (x1, y1) = mk(), mk()
+    outs = []
+    for use_graph in (False, True):
+        tr = fst.ClassifierTrainer(64, 1, 3, DEV)
+        tr.fe.load_state_dict({k: v.detach() for k, v in Pf.items()}); tr.clf.load_state_dict({k: v.detach() for k, v in Pc.items()})
+        if use_graph:
+            snap = {k: v.detach().clone() for k, v in list(tr.fe.state_dict().items()) + list(tr.clf.state_dict().items())}
+            tr.capture(x0, y0, warmup=2)                     # warm-up steps move the state: put it back
+            with torch.no_grad():
+                for k, v in list(tr.fe.state_dict().items()) + list(tr.clf.state_dict().items()):
+                    v.copy_(snap[k])
+                for o in (tr.opt_fe, tr.opt_clf):
+                    for st in o.state.values():
+                        for t in st.values():
+                            if isinstance(t, torch.Tensor):
+                                t.zero_()
+            loss, logits = tr.replay(x1, y1)
+        else:
+            loss, logits = tr.step(x1, y1)
+        torch.cuda.synchronize()
+        outs.append((float(loss), logits.clone(), torch.cat([p.detach().flatten() for p in tr.parameters()]).clone()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-5 * max(1.0, abs(outs[0][0]))
+    close(outs[1][1], outs[0][1], 1e-4, "graph logits")
+    # Parameters: RMSprop's first step is lr*g/sqrt(0.01 g^2) = +-10*lr whatever |g|; conv biases in front of a train-mode
+    # BatchNorm have a zero true gradient, so the SIGN of their rounding noise decides the step (DESIGN.md, "chaotic
+    # trajectory").  Everything with a real gradient agrees; the rest differs by at most 2 * 10 * lr = 0.06.
+    diff = (outs[0][2] - outs[1][2]).abs()
+    assert float(diff.max()) <= 0.061 and float((diff > 1e-4).double().mean()) < 0.05
