@@ -1,8 +1,8 @@
 // CPC InfoNCE cross-Gram (Comparison/SLARDA/train.py:72-76), fused: for each prediction step i the
 // B×B matrix total_i = enc_i · pred_iᵀ is never materialised.  Forward: the Gram product runs on the
 // matrix cores (exact f32 MFMA) with the log-softmax and the diagonal taken on the accumulators.
-// Backward: a workgroup keeps pred_i in LDS ([B][C+1], odd stride → conflict-free lane↔column reads),
-// re-forms 16 rows of the product at a time on the VALU and contracts them with pred / enc.
+// Backward: the same Gram tile re-formed on MFMA, turned into dt in the accumulators, which then feed
+// dpred += dtᵀ·enc directly as an MFMA operand; denc = dt·pred goes through one LDS transpose.
 // The whole loss is ≈1.7 GFLOP per call at B=256, T=256.
 //
 // enc is read in place from the feature tensor through (s_i, s_b, s_c) element strides, so no
@@ -146,7 +146,18 @@ __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
   }
 }
 
-template <int CMAX>
+// Backward on the matrix cores, one workgroup per step i (pred_i staged once), looping over 32-row blocks:
+//   (1) total[32][Bc] as in the forward; dt = (exp(total − lse) − [j == b + col_off])·gout/(B·T) in place in the
+//       accumulators (lane = column j, register s = row k(s,h) = (s&3) + 8(s>>2) + 4h).
+//   (2) dpred[j][c] += Σ_b dt[b][j]·enc[b][c]:  the dt accumulators ARE the A operand (lane = output row j, and the
+//       k index is a dummy: k-step s pairs row k(s,0) on the low half with row k(s,1) on the high half, the B operand
+//       enc[k(s,h)][c] is read to match) — no lane movement, no LDS.  Accumulated over the row blocks in registers.
+//   (3) denc[b][c] = Σ_j dt[b][j]·pred[j][c] sums over dt's COLUMN index: dt goes through LDS once ([32][Bc|1]) and
+//       comes back as the A operand (lane = row b); the four waves split K = Bc and their partial tiles are summed
+//       through LDS.
+// Channels are processed in tiles of 32 (C = 50 → 2), any C; Bc <= 256.
+#define CPC_CT_MAX 8     // channel tiles of 32: C <= 256
+
 __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.t0_dev) {
@@ -154,78 +165,131 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
     p.denc += (long long)p.t0_dev[0] * p.s_i;
   }
   const int i = blockIdx.x;
-  const int B = p.B, Bc = p.Bc, C = p.C, PS = C | 1;
+  const int B = p.B, Bc = p.Bc, C = p.C, PS = C | 1, DS = Bc | 1;
+  const int nct = (C + 31) / 32, ntiles = (Bc + 31) / 32;
   float* predl = lds;                              // [Bc][PS]
-  float* encl = predl + (size_t)Bc * PS;           // [CPC_ROWS][C]
-  float* dtl = encl + CPC_ROWS * C;                // [CPC_ROWS][Bc]
+  float* encl = predl + (size_t)Bc * PS;           // [32][PS]
+  float* dtl = encl + 32 * PS;                     // [32][DS]
+  float* part = dtl + 32 * DS;                     // [4 waves][32][32]  partial denc tiles of one channel tile
+  float* lsel = part + 4 * 32 * 32;                // [32]
   const float* predg = p.pred + (long long)i * Bc * C;
   for (int idx = threadIdx.x; idx < Bc * C; idx += 256) {
     const int j = idx / C, c = idx - j * C;
     predl[j * PS + c] = predg[idx];
   }
-  const float gs = p.gout[0] / ((float)B * (float)p.T);   // d nce / d total = (softmax − I)/(B·T)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int jcol = threadIdx.x;                           // this thread's dpred column (Bc ≤ 256)
-  // dpred is accumulated in registers, CMAX channels of one column per thread; wider features take several passes
-  // over the row blocks (the dt tile is re-formed per pass, denc is written in the first one)
-  for (int c0 = 0; c0 < C; c0 += CMAX) {
-  float dp[CMAX];
-#pragma unroll
-  for (int c = 0; c < CMAX; ++c) dp[c] = 0.f;
+  const float gs = p.gout[0] / ((float)B * (float)p.T);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
 
-  for (int r0 = 0; r0 < B; r0 += CPC_ROWS) {
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < CPC_ROWS * C; idx += 256) {
-      const int r = idx / C, c = idx - r * C;
-      const int b = r0 + r;
-      encl[idx] = b < B ? p.enc[i * p.s_i + b * p.s_b + c * p.s_c] : 0.f;
-    }
-    __syncthreads();
-    for (int r = wave; r < CPC_ROWS; r += 4) {
-      const int b = r0 + r;
-      const float* er = encl + r * C;
-      const float lse = b < B ? p.lse[(long long)i * B + b] : 0.f;
-      for (int j = lane; j < Bc; j += 64) {
-        float v = 0.f;
-        if (b < B) {
-          const float* pj = predl + j * PS;
-          float d = 0.f;
-          for (int c = 0; c < C; ++c) d = fmaf(er[c], pj[c], d);
-          v = (expf(d - lse) - (j == b + p.col_off ? 1.f : 0.f)) * gs;
+  for (int ct0 = 0; ct0 < nct; ct0 += 2) {         // dpred channel tiles kept in registers: two at a time
+    f32x16 dP[CPC_MAXTILES][2];
+#pragma unroll
+    for (int t = 0; t < CPC_MAXTILES; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dP[t][u][r] = 0.f;
+
+    for (int r0 = 0; r0 < B; r0 += 32) {
+      __syncthreads();                             // previous block's readers of encl / dtl / part / lsel are done
+      for (int idx = threadIdx.x; idx < 32 * C; idx += 256) {
+        const int r = idx / C, c = idx - r * C;
+        const int b = r0 + r;
+        encl[r * PS + c] = b < B ? p.enc[i * p.s_i + b * p.s_b + c * p.s_c] : 0.f;
+      }
+      if (threadIdx.x < 32) lsel[threadIdx.x] = r0 + threadIdx.x < B ? p.lse[(long long)i * B + r0 + threadIdx.x] : 0.f;
+      __syncthreads();
+      // (1) total tiles -> dt
+      f32x16 acc[CPC_MAXTILES];
+#pragma unroll
+      for (int t = 0; t < CPC_MAXTILES; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      const float* arow = encl + l31 * PS + half;
+      for (int s = 0; 2 * s < C; ++s) {
+        const bool k_ok = 2 * s + half < C;
+        const float a = k_ok ? arow[2 * s] : 0.f;
+#pragma unroll
+        for (int t = 0; t < CPC_MAXTILES; ++t) {
+          const int j = (wave + 4 * t) * 32 + l31;
+          const float bv = (k_ok && j < Bc) ? predl[j * PS + 2 * s + half] : 0.f;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
         }
-        dtl[r * Bc + j] = v;
+      }
+#pragma unroll
+      for (int t = 0; t < CPC_MAXTILES; ++t) {
+        const int j = (wave + 4 * t) * 32 + l31;
+        const bool col_ok = wave + 4 * t < ntiles && j < Bc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          const int b = r0 + row;
+          float v = 0.f;
+          if (col_ok && b < B) v = (expf(acc[t][r] - lsel[row]) - (j == b + p.col_off ? 1.f : 0.f)) * gs;
+          acc[t][r] = v;
+          if (ct0 == 0 && col_ok) dtl[row * DS + j] = v;            // for (3), first channel pass only
+        }
+      }
+      // (2) dpred tiles += dt^T · enc   (A = the dt accumulators, k-step s <-> rows k(s,0), k(s,1))
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = (ct0 + u) * 32 + l31;
+        if (ct0 + u < nct) {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) {
+            const int k = (s & 3) + 8 * (s >> 2) + 4 * half;
+            const float bv = c < C ? encl[k * PS + c] : 0.f;
+#pragma unroll
+            for (int t = 0; t < CPC_MAXTILES; ++t) dP[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[t][s], bv, dP[t][u], 0, 0, 0);
+          }
+        }
+      }
+      // (3) denc = dt · pred, once per row block (first channel pass), channel tile by channel tile
+      if (ct0 == 0) {
+        __syncthreads();                           // dtl complete
+        for (int ct = 0; ct < nct; ++ct) {
+          f32x16 d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) d[r] = 0.f;
+          const int c = ct * 32 + l31;
+          const int kq = (Bc + 3) / 4;             // this wave's quarter of K = Bc (rounded to even below)
+          const int k_lo = (wave * kq) & ~1, k_hi = min(Bc, ((wave + 1) * kq) & ~1) ;
+          const int k_end = wave == 3 ? Bc : k_hi;
+          for (int k = k_lo; k < k_end; k += 2) {
+            const int kk = k + half;
+            const float a = kk < k_end ? dtl[l31 * DS + kk] : 0.f;
+            const float bv = (kk < k_end && c < C) ? predl[kk * PS + c] : 0.f;
+            d = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, d, 0, 0, 0);
+          }
+          __syncthreads();                         // previous channel tile's partials have been consumed
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = d[r];
+          __syncthreads();
+          for (int o = threadIdx.x; o < 32 * 32; o += 256) {
+            const int row = o >> 5, cc = ct * 32 + (o & 31);
+            const int b = r0 + row;
+            if (b < B && cc < C)
+              p.denc[i * p.s_i + b * p.s_b + cc * p.s_c] = (part[o] + part[1024 + o]) + (part[2048 + o] + part[3072 + o]);
+          }
+        }
       }
     }
-    __syncthreads();
-    // denc[b][c] = Σ_j dt[b][j]·pred[j][c]
-    if (c0 == 0)
-    for (int o = threadIdx.x; o < CPC_ROWS * C; o += 256) {
-      const int r = o / C, c = o - r * C;
-      const int b = r0 + r;
-      if (b >= B) continue;
-      const float* dr = dtl + r * Bc;
-      float s = 0.f;
-      for (int j = 0; j < Bc; ++j) s = fmaf(dr[j], predl[j * PS + c], s);
-      p.denc[i * p.s_i + b * p.s_b + c * p.s_c] = s;
-    }
-    // dpred[j][c] += Σ_b dt[b][j]·enc[b][c]
-    if (jcol < Bc) {
-      for (int r = 0; r < CPC_ROWS; ++r) {
-        const float d = dtl[r * Bc + jcol];
-        const float* er = encl + r * C;
+    // write this pass's dpred channel tiles: acc layout row = j (lane... transposed view): dP[t][u] register r holds
+    // output row (r&3)+8(r>>2)+4h of tile t  =  column index j_local, and lane l31 is the channel
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
-          if (c0 + c < C) dp[c] = fmaf(d, er[c0 + c], dp[c]);
+    for (int t = 0; t < CPC_MAXTILES; ++t) {
+      if (wave + 4 * t >= ntiles) continue;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = (ct0 + u) * 32 + l31;
+        if (ct0 + u >= nct || c >= C) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = (wave + 4 * t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (j < Bc) p.dpred[((long long)i * Bc + j) * C + c] = dP[t][u][r];
+        }
       }
     }
   }
-  if (jcol < Bc) {
-    float* out = p.dpred + ((long long)i * Bc + jcol) * C + c0;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c0 + c < C) out[c] = dp[c];
-  }
-  }   // channel chunks
 }
 
 static int cpc_check(const CpcParams& p, size_t lds_bytes, const char* who) {
@@ -266,14 +330,14 @@ extern "C" int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64
   p.t0_dev = t0_dev;
   p.enc = enc; p.s_i = s_i; p.s_b = s_b; p.s_c = s_c; p.pred = pred; p.lse = const_cast<float*>(lse);
   p.gout = gout; p.denc = denc; p.dpred = dpred; p.T = T; p.B = B; p.C = C; p.Bc = Bc; p.col_off = col_off;
-  const size_t lds_bytes = ((size_t)Bc * (C | 1) + CPC_ROWS * C + (size_t)CPC_ROWS * Bc) * sizeof(float);
+  const size_t lds_bytes = ((size_t)Bc * (C | 1) + 32 * (C | 1) + 32 * (size_t)(Bc | 1) + 4 * 32 * 32 + 32) * sizeof(float);
   if (int rc = cpc_check(p, lds_bytes, "fst_cpc_nce_bwd")) return rc;
   FST_REQUIRE(gout && denc && dpred, "fst_cpc_nce_bwd: null gradient buffer");
-  FST_REQUIRE(Bc <= 256, "fst_cpc_nce_bwd: %d > 256 negatives (columns) not supported yet", Bc);
-  void (*fn)(CpcParams) = C <= 32 ? cpc_bwd_kernel<32> : (C <= 64 ? cpc_bwd_kernel<64> : cpc_bwd_kernel<128>);
+  FST_REQUIRE(Bc <= 128 * CPC_MAXTILES, "fst_cpc_nce_bwd: %d > %d negatives (columns) not supported yet", Bc, 128 * CPC_MAXTILES);
+  FST_REQUIRE(C <= 32 * CPC_CT_MAX, "fst_cpc_nce_bwd: C=%d > %d not supported yet", C, 32 * CPC_CT_MAX);
   if (lds_bytes > 48 * 1024)
-    if (int rc = fst_allow_full_lds((const void*)fn, "fst_cpc_nce_bwd")) return rc;
-  hipLaunchKernelGGL(fn, dim3(T), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    if (int rc = fst_allow_full_lds((const void*)cpc_bwd_kernel, "fst_cpc_nce_bwd")) return rc;
+  hipLaunchKernelGGL(cpc_bwd_kernel, dim3(T), dim3(256), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }
