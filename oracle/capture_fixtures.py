@@ -7,9 +7,15 @@ which never travels to the GPU box).  Usage:
 
 Harness-side shims (the reference files are untouched): ``np.float`` alias,
 ``Tensor.cuda``/``Module.cuda`` → identity (the reference hard-codes ``.cuda()``), and a stub
-``sktime`` module (DataSource.py imports it; never called here).  ``train()`` itself cannot be
+``sktime`` module (DataSource.py imports it).  ``train()`` itself cannot be
 driven (needs ``.ts`` datasets); the joint-step fixture drives the reference MODULES through a
 harness that follows train_and_test.py:539-766 statement by statement.
+
+Besides the module / joint-step fixtures it writes ``phases_small`` (one batch of each of the six pre-training
+phase bodies of train(), from the joint fixture's initial state), ``voting_small`` (lines 281-424 of
+multi_source_voting.py compiled from the reference file and executed on stub loaders / models with preset logits)
+and ``datasource_small`` (the reference's TrainData / TestData classes running on top of the build's sktime-free
+.ts parser, plugged in as the stub sktime's ``load_from_tsfile``).
 
 What is stored is data only: seeds, inputs, state_dicts, outputs, gradients.
 """
