@@ -3,7 +3,11 @@
 OS_CNN + Simplified_NF_WaveGlow + C_DAN (+CPC, GradNorm), synthetic univariate L=512, batch 256 per GPU).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N>1 either way: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (the ranks
+    read RANK / LOCAL_RANK / WORLD_SIZE), or as the plain command — bench.py then starts that launcher itself as a CHILD
+    process before touching the GPU, relays rank 0's JSON line and exits with the child's code.
+    Other BASELINE configs on one GPU: --sources 4 (configs[2]: four independent source->target pipelines, aggregate
+    pairs/s), --c-in 9 --length 5000 --batch B (configs[3]), --length 1024 (configs[4]'s per-GPU shape).
 
 A "step" is one pass of train_and_test.py:539-766 over one batch of 256 (target, source) pairs per GPU:
 forward of every module, the GradNorm partial backward passes, one full backward, all optimiser updates.
@@ -38,16 +42,20 @@ def synthetic_batch(B, C_in, L, n_class, device, seed):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(L: int, pairs: int, steps: int):
+def cpu_baseline(L: int, pairs: int, steps: int, c_in: int = 1):
     """The CPU oracle (oracle/restatement.py, a port of the reference's step) timed on this host's cores on a
-    bounded sample of the same workload.  Baseline only — never the product path."""
+    bounded sample of the same workload.  Baseline only — never the product path.  The sample is `pairs` pairs per
+    step, not the metric's 256: a B=256 step of this path is ~100 s of CPU (the reference's own modules at
+    B=256, L=512 ran ≈2.5 pairs/s on 8 vCPUs; round 1's 16-pair sample on the GPU box's 16 threads gave 2.2-2.3), so
+    two of them plus a warm-up would be most of the bench's few-minutes budget; pairs/s is what is compared.  One more step is timed with autograd anomaly mode ON,
+    as the reference ships (train_and_test.py:24)."""
     from oracle import restatement as R
     # the GPU box gives one GPU a 16-CPU share; torch's default (all visible cores) oversubscribes it 8x
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
     torch.manual_seed(1234)
-    js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=1234)
+    js = R.build_joint_step(L, c_in, L, c_in, 4, 4, seed=1234)
     g = torch.Generator().manual_seed(99)
-    mk = lambda: ((lambda x: (x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True))(torch.randn(pairs, 1, L, generator=g)),
+    mk = lambda: ((lambda x: (x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True))(torch.randn(pairs, c_in, L, generator=g)),
                   torch.randint(4, (pairs,), generator=g))
     (x_t, y_t), (x_s, y_s) = mk(), mk()
     js.step(x_t, y_t, x_s, y_s, epoch=0)                                      # warm-up
@@ -55,6 +63,10 @@ def cpu_baseline(L: int, pairs: int, steps: int):
     for _ in range(steps):
         js.step(x_t, y_t, x_s, y_s, epoch=0)
     dt = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    with torch.autograd.set_detect_anomaly(True, check_nan=True):
+        js.step(x_t, y_t, x_s, y_s, epoch=0)
+    dt_anomaly = time.perf_counter() - t0
     model = "?"
     try:
         with open("/proc/cpuinfo") as f:
@@ -63,8 +75,43 @@ def cpu_baseline(L: int, pairs: int, steps: int):
         pass
     return {"value": pairs / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "cpu_model": model, "host_logical_cpus": os.cpu_count(), "cpus_in_affinity": len(os.sched_getaffinity(0)),
-            "sample": f"joint step S2 (L={L}, C_in=1), {pairs} pairs/step, {steps} timed steps after 1 warm-up "
-                      f"({steps * dt:.0f} s of CPU work), autograd anomaly mode off, {dt:.2f} s/step"}
+            "anomaly_mode_on": {"value": pairs / dt_anomaly, "unit": "samples/s", "steps": 1},
+            "sample": f"joint step S2 (L={L}, C_in={c_in}), {pairs} pairs/step (the metric's batch is 256: see the docstring), "
+                      f"{steps} timed steps after 1 warm-up ({steps * dt:.0f} s of CPU work), autograd anomaly mode off, "
+                      f"{dt:.2f} s/step; + 1 step with anomaly mode on ({dt_anomaly:.1f} s)"}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher environment: start N ranks through torch.distributed.run as a child
+    process (never exec: nothing here has touched the GPU yet, but a child keeps that true whatever is added later),
+    pass its output through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                          # dmabuf IPC only on this pool (RCCL needs it)
+    print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def f32_mode_rate(args):
+    """The same step with every GEMM on the exact-f32 MFMA (FST_MATH=f32), measured by a child process (the arithmetic is
+    fixed at import).  Sits beside the split-bf16 headline so the narrower product arithmetic is visible in the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(2, min(args.steps, 4))), "--warmup", "1",
+           "--batch", str(args.batch), "--length", str(args.length), "--c-in", str(args.c_in), "--sources", str(args.sources),
+           "--plain"]
+    out = subprocess.run(cmd, env=dict(os.environ, FST_MATH="f32"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": (out.stderr or out.stdout)[-400:]}
+    d = json.loads(lines[-1])
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "dtype": d["dtype"],
+            "note": "same workload, FST_MATH=f32: v_mfma_f32_32x32x2_f32 everywhere (bit-exact fp32 FMA chains)"}
 
 
 def classifier_step_rate(fst, device, B: int, L: int, steps: int = 30, warmup: int = 5):
@@ -159,16 +206,24 @@ def main() -> None:
     ap.add_argument("--length", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=6)
-    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
-                    help="graph: the whole step is one captured hipGraph replayed per step (default); eager: launch by launch")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--c-in", type=int, default=1, help="input channels of both domains (configs[3]: 9)")
+    ap.add_argument("--sources", type=int, default=1,
+                    help="independent source->target pipelines trained side by side on this GPU (configs[2]: 4); "
+                         "value = aggregate pairs/s")
+    ap.add_argument("--plain", action="store_true", help="step rate only: no S1 / north-star extras / CPU / f32 legs")
+    ap.add_argument("--mode", choices=["graph", "eager", "auto"], default="graph",
+                    help="graph: the whole step is one captured hipGraph replayed per step — a failed capture is an error "
+                         "(default); eager: launch by launch; auto: graph, falling back to eager with a note on stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     # Rehearsal on a one-GPU box only (never set by the driver): FST_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
@@ -198,29 +253,41 @@ def main() -> None:
         bucket = fst.GradBucket()
 
     torch.manual_seed(1234)                                                   # identical replicas on every rank
-    cfg = fst.JointConfig(L_t=args.length, C_in_t=1, L_s=args.length, C_in_s=1, n_class_t=4, n_class_s=4)
-    trainer = fst.JointTrainer(cfg, device, bucket)
-    x_t, y_t = synthetic_batch(args.batch, 1, args.length, 4, device, 1000 + rank)
-    x_s, y_s = synthetic_batch(args.batch, 1, args.length, 4, device, 2000 + rank)
+    cfg = fst.JointConfig(L_t=args.length, C_in_t=args.c_in, L_s=args.length, C_in_s=args.c_in, n_class_t=4, n_class_s=4)
+    # --sources K: K independent pipelines (one per source domain, main.py:7-11), each with its own modules, optimisers
+    # and source batch, sharing the target batch; one step = every pipeline stepped once.
+    trainers = [fst.JointTrainer(cfg, device, bucket) for _ in range(args.sources)]
+    trainer = trainers[0]
+    x_t, y_t = synthetic_batch(args.batch, args.c_in, args.length, 4, device, 1000 + rank)
+    src = [synthetic_batch(args.batch, args.c_in, args.length, 4, device, 2000 + rank + 97 * k) for k in range(args.sources)]
+    x_s, y_s = src[0]
     T_half = (args.length // 2) // 2
     torch.manual_seed(4321)                                                   # CPC start indices: same on every rank
 
     def draw_t():
         return (int(torch.randint(T_half, (1,))), int(torch.randint(T_half, (1,))))
 
-    mode = args.mode
+    mode = "graph" if args.mode == "auto" else args.mode
     if mode == "graph":
         try:
-            trainer.capture(x_t, y_t, x_s, y_s, epoch=0)
-        except Exception as e:                                                # noqa: BLE001 — report, then run eagerly
+            for tr, (xs, ys) in zip(trainers, src):
+                tr.capture(x_t, y_t, xs, ys, epoch=0)
+        except Exception as e:                                                # noqa: BLE001
+            if args.mode != "auto":
+                raise SystemExit(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); --mode graph does not fall back "
+                                 "(use --mode auto or --mode eager)")
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr, flush=True)
             mode = "eager"
             torch.cuda.synchronize()
 
     def one_step():
-        if mode == "graph":
-            return trainer.replay(x_t, y_t, x_s, y_s, draw_t())
-        return trainer.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=draw_t())
+        rep = None
+        for tr, (xs, ys) in zip(trainers, src):
+            if mode == "graph":
+                rep = tr.replay(x_t, y_t, xs, ys, draw_t())
+            else:
+                rep = tr.step(x_t, y_t, xs, ys, epoch=0, t_samples=draw_t())
+        return rep
 
     for i in range(args.warmup):
         one_step()
@@ -250,7 +317,7 @@ def main() -> None:
     torch.cuda.synchronize()
     ops.KERNEL_TIMER = None
     ms_per_step = 1e3 * dt / args.steps
-    value = world * args.batch * args.steps / dt
+    value = world * args.sources * args.batch * args.steps / dt
 
     if rank == 0:
         ks = timer.summary()
@@ -259,10 +326,14 @@ def main() -> None:
         achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
         conv_ms = sum(v["total_ms"] for v in ks.values()) / n_timer_steps
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")             # PMC passes cannot run inside bench.py
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic, traffic_src = tj["hbm_bytes_per_launch"].get(dom_key), tj["source"]
+        # PMC passes cannot run inside bench.py: the newest committed counter summary that covers this kernel
+        for tname in ("traffic_r02.json", "traffic_r01.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj["hbm_bytes_per_launch"].get(dom_key) is not None:
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"][dom_key], tj["source"]
+                    break
         peak = kernel_peak(dom_key)
         mfma = {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_basis": ("bf16 dense MFMA peak 2516.6 TFLOP/s / 3 MFMAs per split-bf16 product" if peak != F32_MFMA_PEAK_TFLOPS
@@ -291,21 +362,34 @@ def main() -> None:
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16x3" if ops.MATH == "bf16x3" else "f32", "data": "synthetic",
-                "config": {"workload": "configs[1]: full joint step (OS_CNN_res x2 + OS_CNN x3 + WaveGlow(3,50,120) fwd x2 + infer "
-                                       "+ CPC x2 + CDAN + GradNorm + RMSprop/Adam), univariate L=%d, %d pairs/GPU" % (args.length, args.batch),
-                           "global_batch": world * args.batch, "seq_len": args.length, "parallelism": f"dp{world}"},
+                "config": {"workload": "%s: full joint step (OS_CNN_res x2 + OS_CNN x3 + WaveGlow(3,50,120) fwd x2 + infer "
+                                       "+ CPC x2 + CDAN + GradNorm + RMSprop/Adam), %s L=%d, %d pairs/GPU%s"
+                                       % (("configs[2]" if args.sources > 1 else "configs[3]" if args.c_in > 1 else
+                                           "configs[4] per-GPU shape" if args.length == 1024 else "configs[1]"),
+                                          "univariate" if args.c_in == 1 else f"{args.c_in}-channel", args.length, args.batch,
+                                          f", {args.sources} independent source->target pipelines per step" if args.sources > 1 else ""),
+                           "global_batch": world * args.batch, "seq_len": args.length, "c_in": args.c_in, "sources": args.sources,
+                           "parallelism": f"dp{world}"},
                 "mode": mode, "dist_backend": (os.environ.get("FST_BENCH_BACKEND", "nccl") if world > 1 else None),
-                "arithmetic": ("fp32 storage; GEMM products as hi*hi + hi*lo + lo*hi of round-to-nearest bf16 halves on "
-                               "v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error ~5e-6 of the output scale); the "
-                               "omni-scale window kernel and everything pointwise in f32") if ops.MATH == "bf16x3" else "f32 MFMA",
+                "arithmetic": ("fp32 storage; every GEMM-shaped product (WaveGlow convs, omni-scale window kernel, weight "
+                               "gradients, random-layer GEMM) as hi*hi + hi*lo + lo*hi of round-to-nearest bf16 halves on "
+                               "v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error ~5e-6 of the output scale); exact-f32 "
+                               "MFMA for omni-scale layers with < 8 input channels, shapes with L % 4 != 0 and the CPC "
+                               "cross-Gram; everything pointwise in f32") if ops.MATH == "bf16x3" else
+                              "f32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains) for every GEMM-shaped product",
                 "losses": {k: float(rep[k]) for k in ("nf_t", "nf_s", "ce_t", "ce_s", "sl_t", "cdan")},
                 "roofline": roofline}
-        if world == 1:
+        default_shape = args.c_in == 1 and args.sources == 1
+        if world == 1 and not args.plain and default_shape:
             line["s1_classifier_step"] = classifier_step_rate(fst, device, args.batch, args.length)
             line["north_star_extras"] = north_star_extras(fst, ops, trainer, x_t, args.batch, args.length)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.length, args.cpu_pairs, args.cpu_steps)
-            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        if world == 1 and not args.plain and ops.MATH == "bf16x3":
+            del trainers, trainer                                               # the child needs the HBM
+            torch.cuda.empty_cache()
+            line["f32_mode"] = f32_mode_rate(args)
+        if world == 1 and not args.plain and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.length, args.cpu_pairs, args.cpu_steps, args.c_in)
+            line["gpu_over_cpu"] = value / args.sources / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

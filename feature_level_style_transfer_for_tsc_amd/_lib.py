@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
@@ -42,17 +42,17 @@ _SIGNATURES = {
     "fst_conv_wgrad": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P, _I32P, _I32P, c_int,
                                c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fst_row_sum": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_void_p]),
-    "fst_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, c_void_p]),
+    "fst_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, c_int64, c_void_p]),
     "fst_bn_finalize": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_void_p]),
-    "fst_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_void_p]),
-    "fst_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_void_p]),
-    "fst_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "fst_gate_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_void_p]),
-    "fst_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_void_p]),
-    "fst_coupling_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_void_p]),
-    "fst_coupling_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_void_p]),
-    "fst_coupling_inv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_void_p]),
-    "fst_coupling_inv_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_void_p]),
+    "fst_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, c_void_p]),
+    "fst_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_gate_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_coupling_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_coupling_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_coupling_inv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_coupling_inv_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_axpy": (c_int, [_P, _P, c_float, c_int64, c_void_p]),
     "fst_add_slices": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_void_p]),
     "fst_cpc_nce_fwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_void_p]),

@@ -1055,6 +1055,21 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
   bool needs_x1 = false;
   for (int q = 0; q < pv.n_chunks; ++q) needs_x1 |= pv.chunk[4 * q] == 1;
   FST_REQUIRE(!needs_x1 || x1 != nullptr, "fst_conv_gemm: plan reads input 1 but x1 is null");
+  // a batch stride shorter than the rows a sample owns would make the B samples of the launch overlap / overrun
+  {
+    int rows_in[2] = {0, 0};
+    for (int q = 0; q < pv.n_chunks; ++q) {
+      const int32_t* c = pv.chunk + 4 * q;
+      rows_in[c[0]] = rows_in[c[0]] > c[1] + c[2] ? rows_in[c[0]] : c[1] + c[2];
+    }
+    FST_REQUIRE(B == 1 || (x0_bs >= (int64_t)rows_in[0] * L && (!needs_x1 || x1_bs >= (int64_t)rows_in[1] * L)),
+                "fst_conv_gemm: an input batch stride (%lld, %lld) is smaller than its %d / %d channels x L=%d",
+                (long long)x0_bs, (long long)x1_bs, rows_in[0], rows_in[1], L);
+    FST_REQUIRE(B == 1 || ((msplit == 0 || y_bs >= (int64_t)msplit * L) && (res == nullptr || res_bs >= (int64_t)msplit * L) &&
+                           (msplit == M || y2_bs >= (int64_t)(M - m2_start) * L)),
+                "fst_conv_gemm: an output batch stride (y %lld, res %lld, y2 %lld) is smaller than the rows it holds",
+                (long long)y_bs, (long long)res_bs, (long long)y2_bs);
+  }
   const bool pipe = plan_is_pipeable(pv) && pick_conv_gemm_pipe(pv.MB, nb_cfg) != nullptr;
   // 16-byte B-tile loads need every address of a stage row to be 16-B aligned
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1559,6 +1574,17 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   bool needs_x1 = false;
   for (int q = 0; q < pv.n_chunks; ++q) needs_x1 |= pv.chunk[4 * q] == 1;
   FST_REQUIRE(!needs_x1 || x1 != nullptr, "fst_conv_wgrad: plan reads input 1 but x1 is null");
+  {
+    int rows_in[2] = {0, 0};
+    for (int q = 0; q < pv.n_chunks; ++q) {
+      const int32_t* c = pv.chunk + 4 * q;
+      rows_in[c[0]] = rows_in[c[0]] > c[1] + c[2] ? rows_in[c[0]] : c[1] + c[2];
+    }
+    FST_REQUIRE(B == 1 || (x0_bs >= (int64_t)rows_in[0] * L && (!needs_x1 || x1_bs >= (int64_t)rows_in[1] * L) &&
+                           dy_bs >= (int64_t)msplit * L && (msplit == M || dy2_bs >= (int64_t)(M - msplit) * L)),
+                "fst_conv_wgrad: a batch stride (x0 %lld, x1 %lld, dy %lld, dy2 %lld) is smaller than the rows it strides over",
+                (long long)x0_bs, (long long)x1_bs, (long long)dy_bs, (long long)dy2_bs);
+  }
   for (int i = 0; i < pv.n_items; ++i) {
     const int32_t* it = pv.item + 4 * i;
     FST_REQUIRE(it[1] < pv.n_chunks && (it[1] < 0 || (it[0] >= 0 && it[0] < pv.n_mgroups && it[2] >= 0)),

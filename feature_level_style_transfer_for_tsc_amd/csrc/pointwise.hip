@@ -48,6 +48,15 @@ __device__ __forceinline__ void block_sum2(float& a, float& b) {
   __syncthreads();
 }
 
+// Every launcher below sizes its grid from (B, C, L) and walks B*C*L contiguous elements per tensor.  The caller passes
+// the element count of the tensors it actually holds (`numel`) separately, so a batch argument that does not describe
+// them — e.g. a global (all-rank) batch handed over as the launch batch — is refused on the host instead of walking
+// past the end of the allocation (the GPU memory fault of round 1, DESIGN.md "Fault log").
+#define FST_REQUIRE_EXTENT(who, B, C, L, numel)                                                             \
+  FST_REQUIRE((long long)(B) * (long long)(C) * (long long)(L) == (long long)(numel),                        \
+              "%s: B*C*L = %d*%d*%d does not match the tensors' element count %lld", who, (int)(B), (int)(C), (int)(L), \
+              (long long)(numel))
+
 #define CH_SPLIT 16   // blocks per channel for the (B,L) reductions
 
 // ---------------------------------------------------------------- row sums (bias / beta gradients)
@@ -64,6 +73,7 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* x, long long 
 
 extern "C" int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, void* stream) {
   FST_REQUIRE(x && out && B > 0 && C > 0 && L > 0, "fst_row_sum: bad arguments");
+  FST_REQUIRE(B == 1 || x_bs >= (int64_t)C * L, "fst_row_sum: batch stride %lld < C*L = %lld", (long long)x_bs, (long long)C * L);
   hipLaunchKernelGGL(row_sum_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, x,
                      (long long)x_bs, B, C, L, out);
   FST_LAUNCH_CHECK();
@@ -89,8 +99,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int B, in
   }
 }
 
-extern "C" int fst_bn_stats(const float* y, int B, int C, int L, float* sums, void* stream) {
+extern "C" int fst_bn_stats(const float* y, int B, int C, int L, float* sums, int64_t numel, void* stream) {
   FST_REQUIRE(y && sums && B > 0 && C > 0 && L > 0, "fst_bn_stats: bad arguments");
+  FST_REQUIRE_EXTENT("fst_bn_stats", B, C, L, numel);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, y, B, C, L, sums);
   FST_LAUNCH_CHECK();
   return 0;
@@ -151,8 +162,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, const flo
 }
 
 extern "C" int fst_bn_apply(const float* y, const float* stats, const float* res, const float* res_stats, float* out,
-                            int B, int C, int L, int relu, void* stream) {
+                            int B, int C, int L, int relu, int64_t numel, void* stream) {
   FST_REQUIRE(y && stats && out && B > 0 && C > 0 && L > 0, "fst_bn_apply: bad arguments");
+  FST_REQUIRE_EXTENT("fst_bn_apply", B, C, L, numel);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, y, stats, res, res_stats, out, C, L, relu);
   FST_LAUNCH_CHECK();
   return 0;
@@ -180,8 +192,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, con
 }
 
 extern "C" int fst_bn_bwd_reduce(const float* dy, const float* y, const float* out, const float* stats, int B, int C,
-                                 int L, int relu, float* red, void* stream) {
-  FST_REQUIRE(dy && y && stats && red && (!relu || out), "fst_bn_bwd_reduce: bad arguments");
+                                 int L, int relu, float* red, int64_t numel, void* stream) {
+  FST_REQUIRE(dy && y && stats && red && (!relu || out) && B > 0 && C > 0 && L > 0, "fst_bn_bwd_reduce: bad arguments");
+  FST_REQUIRE_EXTENT("fst_bn_bwd_reduce", B, C, L, numel);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, dy, y,
                      out, stats, B, C, L, relu, red);
   FST_LAUNCH_CHECK();
@@ -205,9 +218,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
 }
 
 extern "C" int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
-                                float* dx, int B, int C, int L, int relu, int train, int B_total, void* stream) {
+                                float* dx, int B, int C, int L, int relu, int train, int B_total, int64_t numel,
+                                void* stream) {
   FST_REQUIRE(dy && y && stats && dx && (!relu || out) && (!train || red), "fst_bn_bwd_apply: bad arguments");
   FST_REQUIRE(B > 0 && C > 0 && L > 0 && B_total >= B, "fst_bn_bwd_apply: B=%d C=%d L=%d B_total=%d", B, C, L, B_total);
+  FST_REQUIRE_EXTENT("fst_bn_bwd_apply", B, C, L, numel);     // the launch walks B (not B_total) samples
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, y, out, stats, red, dx, C, L,
                      relu, train, 1.0f / ((float)B_total * (float)L));
   FST_LAUNCH_CHECK();
@@ -230,8 +245,9 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(float* g, float* acts, in
   }
 }
 
-extern "C" int fst_gate_fwd(float* g_ts, float* acts, int B, int n, int L, void* stream) {
+extern "C" int fst_gate_fwd(float* g_ts, float* acts, int B, int n, int L, int64_t numel_acts, void* stream) {
   FST_REQUIRE(g_ts && acts && B > 0 && n > 0 && L > 0, "fst_gate_fwd: bad arguments");
+  FST_REQUIRE_EXTENT("fst_gate_fwd", B, n, L, numel_acts);
   long long blocks = ((long long)n * L + 255) / 256;
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, g_ts, acts, n, L);
@@ -254,8 +270,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* ts, const fl
   }
 }
 
-extern "C" int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, int L, void* stream) {
+extern "C" int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, int L, int64_t numel_acts,
+                            void* stream) {
   FST_REQUIRE(ts && dacts && dg && B > 0 && n > 0 && L > 0, "fst_gate_bwd: bad arguments");
+  FST_REQUIRE_EXTENT("fst_gate_bwd", B, n, L, numel_acts);
   long long blocks = ((long long)n * L + 255) / 256;
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, ts, dacts, dg, n, L);
@@ -278,19 +296,22 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(const float* u, const
   }
 }
 
-static int launch_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int mode, void* stream) {
+static int launch_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int mode, int64_t numel,
+                               void* stream) {
   FST_REQUIRE(u && o && xn && B > 0 && h > 0 && L > 0, "fst_coupling: bad arguments");
+  FST_REQUIRE_EXTENT("fst_coupling", B, 2 * h, L, numel);
   long long blocks = ((long long)h * L + 255) / 256;
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(coupling_fwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, xn, h, L, mode);
   FST_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, void* stream) {
-  return launch_coupling_fwd(u, o, xn, B, h, L, 0, stream);
+extern "C" int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int64_t numel, void* stream) {
+  return launch_coupling_fwd(u, o, xn, B, h, L, 0, numel, stream);
 }
-extern "C" int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, void* stream) {
-  return launch_coupling_fwd(x, o, xn, B, h, L, 1, stream);
+extern "C" int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, int64_t numel,
+                                    void* stream) {
+  return launch_coupling_fwd(x, o, xn, B, h, L, 1, numel, stream);
 }
 
 // forward-coupling backward.  dxn: grad of xn (2h ch); dlogs: extra grad flowing into log_s (may be null)
@@ -313,8 +334,9 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(const float* u, const
 }
 
 extern "C" int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, float* du,
-                                float* d_o, int B, int h, int L, void* stream) {
+                                float* d_o, int B, int h, int L, int64_t numel, void* stream) {
   FST_REQUIRE(u && o && dxn && du && d_o && B > 0 && h > 0 && L > 0, "fst_coupling_bwd: bad arguments");
+  FST_REQUIRE_EXTENT("fst_coupling_bwd", B, 2 * h, L, numel);
   long long blocks = ((long long)h * L + 255) / 256;
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, dxn, dlogs, du, d_o, h, L);
@@ -340,8 +362,9 @@ __global__ __launch_bounds__(256) void coupling_inv_bwd_kernel(const float* xn, 
 }
 
 extern "C" int fst_coupling_inv_bwd(const float* xn, const float* o, const float* dxn, float* dx, float* d_o, int B,
-                                    int h, int L, void* stream) {
+                                    int h, int L, int64_t numel, void* stream) {
   FST_REQUIRE(xn && o && dxn && dx && d_o && B > 0 && h > 0 && L > 0, "fst_coupling_inv_bwd: bad arguments");
+  FST_REQUIRE_EXTENT("fst_coupling_inv_bwd", B, 2 * h, L, numel);
   long long blocks = ((long long)h * L + 255) / 256;
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(coupling_inv_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, xn, o, dxn, dx, d_o, h, L);
@@ -376,6 +399,8 @@ __global__ __launch_bounds__(256) void add_slices_kernel(float* dst, long long d
 extern "C" int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,
                               int B, int C, int L, void* stream) {
   FST_REQUIRE(dst && a && B > 0 && C > 0 && L > 0, "fst_add_slices: bad arguments");
+  FST_REQUIRE(B == 1 || (dst_bs >= (int64_t)C * L && a_bs >= (int64_t)C * L && (!b || b_bs >= (int64_t)C * L)),
+              "fst_add_slices: a batch stride is smaller than the C*L = %lld slice it strides over", (long long)C * L);
   long long blocks = ((long long)C * L + 255) / 256;
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(add_slices_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, dst, (long long)dst_bs, a,

@@ -120,6 +120,26 @@ def _ncl(t: Tensor, name: str) -> Tuple[int, int]:
     return t.stride(0), t.size(2)
 
 
+def _same_numel(*tensors: Optional[Tensor]) -> int:
+    """Element count shared by the contiguous tensors a pointwise launch walks — taken from the tensors themselves, never
+    from the (B, C, L) the launch is given, so the library can refuse a batch argument that does not describe them."""
+    ts = [t for t in tensors if t is not None]
+    n = ts[0].numel()
+    for t in ts:
+        if t.numel() != n or not t.is_contiguous():
+            raise ValueError(f"pointwise launch over tensors of different extents / non-contiguous: {[tuple(x.shape) for x in ts]}")
+    return n
+
+
+def _gate_numel(acts: Tensor, *pairs: Tensor) -> int:
+    """Element count of the [B, n, L] side of a gate launch; the [B, 2n, L] tensors must be exactly twice that."""
+    n = _same_numel(acts)
+    for t in pairs:
+        if t.numel() != 2 * n or not t.is_contiguous():
+            raise ValueError(f"gate launch: {tuple(t.shape)} is not the contiguous [B, 2n, L] partner of {tuple(acts.shape)}")
+    return n
+
+
 def _wsrc(t: Optional[Tensor], off0: int, sm: int, sc: int, st: int) -> WSrc:
     return WSrc(ptr(t) if t is not None else None, off0, sm, sc, st)
 
@@ -538,7 +558,7 @@ def _bn_stats(y: Tensor, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tenso
     sums = None
     if training:
         sums = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
-        check(lib.fst_bn_stats(ptr(y), B, C, L, ptr(sums), stream_ptr()), "fst_bn_stats")
+        check(lib.fst_bn_stats(ptr(y), B, C, L, ptr(sums), y.numel(), stream_ptr()), "fst_bn_stats")
         B_total = _dist.sum_over_ranks_(sums) * B        # global-batch mode: moments over every rank's samples (SyncBN)
     else:
         B_total = B
@@ -552,7 +572,8 @@ def _bn_backward(dy: Tensor, y: Tensor, out: Optional[Tensor], stats: Tensor, re
     lib = _lib.load()
     B, C, L = y.shape
     red = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
-    check(lib.fst_bn_bwd_reduce(ptr(dy), ptr(y), ptr(out), ptr(stats), B, C, L, int(relu), ptr(red), stream_ptr()),
+    check(lib.fst_bn_bwd_reduce(ptr(dy), ptr(y), ptr(out), ptr(stats), B, C, L, int(relu), ptr(red), _same_numel(dy, y, out),
+                                stream_ptr()),
           "fst_bn_bwd_reduce")
     dx = None
     if need_dx:
@@ -564,7 +585,7 @@ def _bn_backward(dy: Tensor, y: Tensor, out: Optional[Tensor], stats: Tensor, re
             red_g = red.clone()
             B_total = _dist.sum_over_ranks_(red_g) * B
         check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(red_g), ptr(dx), B, C, L, int(relu),
-                                   int(training), B_total, stream_ptr()), "fst_bn_bwd_apply")
+                                   int(training), B_total, _same_numel(dy, y, out, dx), stream_ptr()), "fst_bn_bwd_apply")
     return dx, red[C:], red[:C]                                   # dx, dgamma, dbeta
 
 
@@ -578,7 +599,8 @@ class BNActFn(torch.autograd.Function):
         B, C, L = y.shape
         stats = _bn_stats(y, gamma, beta, rmean, rvar, training, eps, momentum)
         out = torch.empty_like(y)
-        check(lib.fst_bn_apply(ptr(y), ptr(stats), None, None, ptr(out), B, C, L, int(relu), stream_ptr()), "fst_bn_apply")
+        check(lib.fst_bn_apply(ptr(y), ptr(stats), None, None, ptr(out), B, C, L, int(relu), _same_numel(y, out), stream_ptr()),
+              "fst_bn_apply")
         ctx.save_for_backward(y, out, stats)
         ctx.relu, ctx.training = relu, training
         return out
@@ -602,7 +624,8 @@ class BNAddBNReluFn(torch.autograd.Function):
         sa = _bn_stats(ya, ga, ba, rma, rva, training, eps, momentum)
         sb = _bn_stats(yb, gb, bb, rmb, rvb, training, eps, momentum)
         out = torch.empty_like(ya)
-        check(lib.fst_bn_apply(ptr(ya), ptr(sa), ptr(yb), ptr(sb), ptr(out), B, C, L, 1, stream_ptr()), "fst_bn_apply")
+        check(lib.fst_bn_apply(ptr(ya), ptr(sa), ptr(yb), ptr(sb), ptr(out), B, C, L, 1, _same_numel(ya, yb, out), stream_ptr()),
+              "fst_bn_apply")
         ctx.save_for_backward(ya, yb, out, sa, sb)
         ctx.training = training
         return out
@@ -660,7 +683,7 @@ class WNFn(torch.autograd.Function):
         for i in range(nl):
             g = S.ins[i].forward(a, u0, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], bias_g[i])
             acts = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
-            check(lib.fst_gate_fwd(ptr(g), ptr(acts), B, n, L, stream_ptr()), "fst_gate_fwd")
+            check(lib.fst_gate_fwd(ptr(g), ptr(acts), B, n, L, _gate_numel(acts, g), stream_ptr()), "fst_gate_fwd")
             ts_list.append(g)
             acts_list.append(acts)
             if i < nl - 1:
@@ -724,7 +747,8 @@ class WNFn(torch.autograd.Function):
                     d_rs_b[i] = torch.cat([row_sum(d_a), d_out_sum])
             # ---- through the gate
             dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
-            check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, stream_ptr()), "fst_gate_bwd")
+            check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]), stream_ptr()),
+                  "fst_gate_bwd")
             if need_w:
                 dw0, dw1 = S.ins[i].grad_w(a_list[i], u0, dg)
                 d_in_w[i] = dw0
@@ -752,7 +776,7 @@ class CouplingFn(torch.autograd.Function):
         u, o = u.contiguous(), o.contiguous()
         B, C, L = u.shape
         xn = torch.empty_like(u)
-        check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, stream_ptr()), "fst_coupling_fwd")
+        check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, _same_numel(u, o, xn), stream_ptr()), "fst_coupling_fwd")
         ctx.save_for_backward(u, o)
         return xn
 
@@ -762,8 +786,9 @@ class CouplingFn(torch.autograd.Function):
         u, o = ctx.saved_tensors
         B, C, L = u.shape
         du, d_o = torch.empty_like(u), torch.empty_like(o)
-        check(lib.fst_coupling_bwd(ptr(u), ptr(o), ptr(dxn.contiguous()), None, ptr(du), ptr(d_o), B, C // 2, L,
-                                   stream_ptr()), "fst_coupling_bwd")
+        dxn = dxn.contiguous()
+        check(lib.fst_coupling_bwd(ptr(u), ptr(o), ptr(dxn), None, ptr(du), ptr(d_o), B, C // 2, L,
+                                   _same_numel(u, o, dxn, du, d_o), stream_ptr()), "fst_coupling_bwd")
         return du, d_o
 
 
@@ -776,7 +801,8 @@ class CouplingInvFn(torch.autograd.Function):
         x, o = x.contiguous(), o.contiguous()
         B, C, L = x.shape
         xn = torch.empty_like(x)
-        check(lib.fst_coupling_inv_fwd(ptr(x), ptr(o), ptr(xn), B, C // 2, L, stream_ptr()), "fst_coupling_inv_fwd")
+        check(lib.fst_coupling_inv_fwd(ptr(x), ptr(o), ptr(xn), B, C // 2, L, _same_numel(x, o, xn), stream_ptr()),
+              "fst_coupling_inv_fwd")
         ctx.save_for_backward(xn, o)
         return xn
 
@@ -786,8 +812,9 @@ class CouplingInvFn(torch.autograd.Function):
         xn, o = ctx.saved_tensors
         B, C, L = xn.shape
         dx, d_o = torch.empty_like(xn), torch.empty_like(o)
-        check(lib.fst_coupling_inv_bwd(ptr(xn), ptr(o), ptr(dxn.contiguous()), ptr(dx), ptr(d_o), B, C // 2, L,
-                                       stream_ptr()), "fst_coupling_inv_bwd")
+        dxn = dxn.contiguous()
+        check(lib.fst_coupling_inv_bwd(ptr(xn), ptr(o), ptr(dxn), ptr(dx), ptr(d_o), B, C // 2, L,
+                                       _same_numel(xn, o, dxn, dx, d_o), stream_ptr()), "fst_coupling_inv_bwd")
         return dx, d_o
 
 

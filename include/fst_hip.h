@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 3
+#define FST_ABI_VERSION 4
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -127,7 +127,11 @@ int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, v
  * and the ReLU / residual add at :74, :179.
  * stats layout (float[4*C]): mean | invstd | scale | shift   (scale = γ·invstd, shift = β − mean·scale)
  * ------------------------------------------------------------------------------------------- */
-int fst_bn_stats(const float* y, int B, int C, int L, float* sums /* [2*C], zeroed by caller */, void* stream);
+/* `numel` (here and below): the element count of the contiguous [B, C, L] tensors the launch walks, taken by the caller
+ * from the tensors it holds — NOT recomputed from B, C, L.  The launcher refuses B*C*L != numel before launching, so a
+ * batch argument that does not describe the buffers (the cause of round 1's GPU memory fault: the all-rank batch
+ * passed as the launch batch of fst_bn_bwd_apply) is an error return, never an out-of-bounds walk. */
+int fst_bn_stats(const float* y, int B, int C, int L, float* sums /* [2*C], zeroed by caller */, int64_t numel, void* stream);
 /* sums = (Σx, Σx²) over B_total·L samples per channel: B_total is the batch the moments run over — the local batch,
  * or in global-batch data parallelism (SyncBN) the sum of every rank's batch after the caller all-reduced sums. */
 int fst_bn_finalize(const float* sums, const float* gamma, const float* beta,
@@ -135,31 +139,31 @@ int fst_bn_finalize(const float* sums, const float* gamma, const float* beta,
                     int B_total, int C, int L, float eps, float momentum, float* stats, void* stream);
 /* out = act(y*scale + shift (+ res*res_scale + res_shift | + res)) */
 int fst_bn_apply(const float* y, const float* stats, const float* res, const float* res_stats,
-                 float* out, int B, int C, int L, int relu, void* stream);
+                 float* out, int B, int C, int L, int relu, int64_t numel, void* stream);
 /* reductions for backward: red[c] = Σ dyʹ, red[C+c] = Σ dyʹ·x̂, with dyʹ = dy·[out>0] when relu */
 int fst_bn_bwd_reduce(const float* dy, const float* y, const float* out, const float* stats,
-                      int B, int C, int L, int relu, float* red /* [2*C] zeroed */, void* stream);
+                      int B, int C, int L, int relu, float* red /* [2*C] zeroed */, int64_t numel, void* stream);
 /* dx = scale·(dyʹ − red0/N − x̂·red1/N) in train mode, scale·dyʹ in eval mode; N = B_total·L.  B is the batch of
  * the tensors (launch shape); B_total >= B the batch red was summed over (= B, or all ranks' batches for SyncBN). */
 int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
-                     float* dx, int B, int C, int L, int relu, int train, int B_total, void* stream);
+                     float* dx, int B, int C, int L, int relu, int train, int B_total, int64_t numel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * WaveGlow pieces — Simplified_NF_WaveGlow.py
  * ------------------------------------------------------------------------------------------- */
 /* gate (:44-54): g[B,2n,L] → t=tanh(g[:n]), s=sigmoid(g[n:]) written back over g; acts=t·s */
-int fst_gate_fwd(float* g_ts, float* acts, int B, int n, int L, void* stream);
+int fst_gate_fwd(float* g_ts, float* acts, int B, int n, int L, int64_t numel_acts, void* stream);
 /* dg[:n] = dacts·s·(1−t²), dg[n:] = dacts·t·s·(1−s) */
-int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, int L, void* stream);
+int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, int L, int64_t numel_acts, void* stream);
 /* affine coupling (:173-178): xn[:, :h]=u[:, :h]; xn[:, h:] = exp(o[:, h:])·u[:, h:] + o[:, :h] */
-int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, void* stream);
+int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int64_t numel, void* stream);
 /* backward of the above given dxn and (added) d_logs; writes du (full 2h channels: du[:, :h]=dxn[:, :h]) and do */
 int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs,
-                     float* du, float* d_o, int B, int h, int L, void* stream);
+                     float* du, float* d_o, int B, int h, int L, int64_t numel, void* stream);
 /* inverse coupling (:193-196): xn[:, h:] = (x[:, h:] − o[:, :h]) / exp(o[:, h:]) */
-int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, void* stream);
+int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, int64_t numel, void* stream);
 int fst_coupling_inv_bwd(const float* xn, const float* o, const float* dxn,
-                         float* dx, float* d_o, int B, int h, int L, void* stream);
+                         float* dx, float* d_o, int B, int h, int L, int64_t numel, void* stream);
 
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */

@@ -217,10 +217,10 @@ def test_gate_and_coupling():
     lib = _lib.load()
     gd = gg.detach().float().to(DEV).clone()
     ad = torch.empty(B, n, L, device=DEV)
-    _lib.check(lib.fst_gate_fwd(gd.data_ptr(), ad.data_ptr(), B, n, L, _lib.stream_ptr()), "gate_fwd")
+    _lib.check(lib.fst_gate_fwd(gd.data_ptr(), ad.data_ptr(), B, n, L, ad.numel(), _lib.stream_ptr()), "gate_fwd")
     assert_close(ad, acts, 1e-5, "gate acts")
     dg = torch.empty(B, 2 * n, L, device=DEV)
-    _lib.check(lib.fst_gate_bwd(gd.data_ptr(), dacts.float().to(DEV).data_ptr(), dg.data_ptr(), B, n, L, _lib.stream_ptr()), "gate_bwd")
+    _lib.check(lib.fst_gate_bwd(gd.data_ptr(), dacts.float().to(DEV).data_ptr(), dg.data_ptr(), B, n, L, ad.numel(), _lib.stream_ptr()), "gate_bwd")
     assert_close(dg, gg.grad, 1e-5, "gate grad")
 
     h = 7
@@ -306,3 +306,61 @@ def test_argument_errors_are_reported_not_launched():
         ops.conv_gemm(plan, a, x, None, None, 2, 16, 999, torch.empty(2, 8, 16, device=DEV))
     with pytest.raises(ValueError):
         ops.conv_gemm(plan, a, x.transpose(1, 2), None, None, 2, 16, 8, torch.empty(2, 8, 16, device=DEV))
+
+
+def test_batch_norm_global_batch_arguments_stay_inside_their_buffers():
+    """Round-1 fault class (DESIGN.md "Fault log"): the SyncBN path hands the kernels TWO batches — B, the samples the
+    tensors hold (launch extent), and B_total >= B, the samples the moments were summed over (only a divisor).  Calling
+    fst_bn_finalize / fst_bn_bwd_apply with B_total = 3*B on buffers padded with canaries must (1) leave the padding
+    untouched, (2) divide by B_total*L, and (3) a launch batch that does not describe the buffers is refused on the host."""
+    from feature_level_style_transfer_for_tsc_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    B, C, L, PAD, CANARY = 4, 6, 40, 4096, 1234.5
+    n = B * C * L
+
+    def padded(src=None):
+        buf = torch.full((PAD + n + PAD,), CANARY, device=DEV)
+        body = buf[PAD: PAD + n].view(B, C, L)
+        if src is not None:
+            body.copy_(src)
+        return buf, body
+
+    y_h, dy_h = torch.randn(B, C, L, generator=g), torch.randn(B, C, L, generator=g)
+    (ybuf, y), (dybuf, dy), (dxbuf, dx) = padded(y_h), padded(dy_h), padded()
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    rmean, rvar = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    sums = torch.zeros(2 * C, device=DEV)
+    _lib.check(lib.fst_bn_stats(y.data_ptr(), B, C, L, sums.data_ptr(), n, _lib.stream_ptr()), "bn_stats")
+    B_total = 3 * B
+    sums_g = sums * 3                                               # as if two more ranks held the same samples
+    stats = torch.empty(4 * C, device=DEV)
+    _lib.check(lib.fst_bn_finalize(sums_g.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), 1,
+                                   B_total, C, L, 1e-5, 0.1, stats.data_ptr(), _lib.stream_ptr()), "bn_finalize")
+    assert_close(stats[:C], y_h.mean(dim=(0, 2)), 1e-5, "mean over B_total*L samples")
+    red = torch.zeros(2 * C, device=DEV)
+    _lib.check(lib.fst_bn_bwd_reduce(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), B, C, L, 0, red.data_ptr(), n,
+                                     _lib.stream_ptr()), "bn_bwd_reduce")
+    red_g = red * 3
+    _lib.check(lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), dx.data_ptr(), B, C, L,
+                                    0, 1, B_total, n, _lib.stream_ptr()), "bn_bwd_apply")
+    torch.cuda.synchronize()
+    for name, buf in (("y", ybuf), ("dy", dybuf), ("dx", dxbuf)):
+        assert bool((buf[:PAD] == CANARY).all()) and bool((buf[PAD + n:] == CANARY).all()), f"{name}: padding was written"
+    # the same formula in fp64: means over the B_total*L global samples (three copies of the local ones)
+    yd, dyd = y_h.double(), dy_h.double()
+    mean, var = yd.mean(dim=(0, 2), keepdim=True), yd.var(dim=(0, 2), unbiased=False, keepdim=True)
+    xh = (yd - mean) / torch.sqrt(var + 1e-5)
+    want = gamma.double().cpu().view(1, C, 1) / torch.sqrt(var + 1e-5) * (
+        dyd - dyd.mean(dim=(0, 2), keepdim=True) - xh * (dyd * xh).mean(dim=(0, 2), keepdim=True))
+    assert_close(dx, want, 1e-4, "dx with B_total = 3B")
+    # (3) the round-1 bug itself — the global batch passed as the launch batch — is now an error return, not a walk
+    rc = lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), dx.data_ptr(), B_total, C, L,
+                              0, 1, B_total, n, _lib.stream_ptr())
+    assert rc < 0 and b"element count" in lib.fst_last_error()
+    rc = lib.fst_bn_apply(y.data_ptr(), stats.data_ptr(), None, None, dx.data_ptr(), B_total, C, L, 0, n, _lib.stream_ptr())
+    assert rc < 0
+    rc = lib.fst_gate_fwd(y.data_ptr(), dx.data_ptr(), 2 * B, C, L, n, _lib.stream_ptr())
+    assert rc < 0
+    torch.cuda.synchronize()
+    assert bool((dxbuf[:PAD] == CANARY).all()) and bool((dxbuf[PAD + n:] == CANARY).all())
