@@ -28,11 +28,14 @@ import torch.distributed as dist
 
 
 class GradBucket:
-    def __init__(self, process_group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, process_group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
+        """``always_reduce``: issue the collectives even in a one-rank group (a no-op numerically) — lets a one-GPU box
+        execute the RCCL code path end to end (tests/test_gpu_dist.py)."""
         if not dist.is_initialized():
             raise RuntimeError("GradBucket needs an initialised torch.distributed process group")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.always_reduce = always_reduce
         self._flat: Optional[torch.Tensor] = None
 
     def _buffer(self, n: int, like: torch.Tensor) -> torch.Tensor:
@@ -43,7 +46,7 @@ class GradBucket:
     def all_reduce(self, params: Iterable[torch.nn.Parameter]) -> None:
         """Average ``.grad`` of every parameter that has one, in place, with ONE collective."""
         grads: List[torch.Tensor] = [p.grad for p in params if p.grad is not None]
-        if not grads or self.world == 1:
+        if not grads or (self.world == 1 and not self.always_reduce):
             return
         n = sum(g.numel() for g in grads)
         flat = self._buffer(n, grads[0])
@@ -57,7 +60,7 @@ class GradBucket:
         torch._foreach_copy_(grads, views)
 
     def mean_scalars(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.world == 1 and not self.always_reduce:
             return t
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

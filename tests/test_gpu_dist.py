@@ -201,3 +201,68 @@ def test_bench_data_parallel_path_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 32
     assert d["mode"] == "graph" and d["dist_backend"] == "gloo" and d["scaling"] == "weak"
     assert d["value"] > 0 and d["steps"] == 2 and d["warmup"] == 1 and "roofline" in d and "cpu_baseline" not in d
+
+
+def test_plain_bench_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher environment (how a user — or a driver without torchrun — calls it):
+    bench.py starts torch.distributed.run itself as a child before touching the GPU, relays rank 0's single JSON line and
+    exits with the child's code.  One-device rehearsal switches as above."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(FST_BENCH_ONE_DEVICE="1", FST_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+           "--length", "128"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["mode"] == "graph" and d["value"] > 0
+    # a rank that fails must fail the command: --gpus 2 under a launcher environment that says otherwise
+    bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root, capture_output=True, text=True,
+                         timeout=300)
+    assert bad.returncode != 0
+
+
+def _worker_rccl(rank, world, port, q):
+    """One rank, backend "nccl" (= RCCL on ROCm): communicator init, a raw all-reduce, the gradient bucket and the 10-scalar
+    average issued for real (always_reduce), eagerly and between the two captured graphs of the data-parallel step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import feature_level_style_transfer_for_tsc_amd as fst
+    t = torch.arange(4096, device=dev, dtype=torch.float32)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(4096, dtype=torch.float32))
+    assert dist.get_backend() == "nccl"
+    bucket = fst.GradBucket(always_reduce=True)
+    tr, meta = _build_small_trainer(fst, dev, bucket, "ddp")
+    ref, _ = _build_small_trainer(fst, dev, None, "ddp")
+    (x_t, y_t), (x_s, y_s) = _global_data(meta, meta["B"])
+    x_t, y_t, x_s, y_s = (v.to(dev) for v in (x_t, y_t, x_s, y_s))
+    a = tr.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=(2, 5))
+    b = ref.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=(2, 5))
+    eager_same = all(abs(float(a[k]) - float(b[k])) <= 1e-5 * max(1.0, abs(float(b[k]))) for k in ("nf_t", "ce_t", "cdan", "sl_s"))
+    torch.manual_seed(9)
+    tr.capture(x_t, y_t, x_s, y_s, epoch=0)
+    rep = tr.replay(x_t, y_t, x_s, y_s, (1, 3))
+    torch.cuda.synchronize()
+    q.put((0, eager_same, len(tr._graphs), float(rep["w_t"].sum()), bool(torch.isfinite(rep["nf_t"]))))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_data_parallel_step_on_one_rank():
+    """RCCL itself (backend "nccl") has to have executed at least once before the 8-GPU driver run: world size 1 on this
+    box's single GPU, with the bucket forced to issue its collectives."""
+    world, port = 1, 29677
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run_worker, args=("_worker_rccl", 0, world, port, q))]
+    procs[0].start()
+    (_, eager_same, n_graphs, w_sum, finite), = _collect(q, world, procs)
+    assert eager_same and n_graphs == 2 and abs(w_sum - 7.0) < 1e-4 and finite
