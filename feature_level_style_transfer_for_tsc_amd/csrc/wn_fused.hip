@@ -1,0 +1,452 @@
+// Fused WaveGlow WN layer for gfx950 (Simplified_NF_WaveGlow.py:101-123, gate :44-54).
+//
+// One launch per layer and direction instead of three:
+//
+//   forward   g = W_in (*) a  (3 dilated taps, n channels each) + W_cond · u0 + (b_in + b_cond)        GEMM 1
+//             t = tanh(g[:n]),  s = sigmoid(g[n:]),  acts = t·s                       in registers
+//             r = W_rs · acts + b_rs;   a_next = a + r[:n];   out (+)= r[n:]                          GEMM 2
+//             (last layer: W_rs has n rows, all of them skip rows: out += r)
+//   backward  dacts = W_rsᵀ · [d_a_next ; d_out]                                                     GEMM 3
+//             dg[:n] = dacts·s·(1−t²),  dg[n:] = dacts·t·s·(1−s)                      in registers
+//
+// so the [B, 2n, L] pre-activation never reaches HBM and acts is (optionally) never written: per layer forward the
+// traffic is  a + u0 + out (read)  and  a_next + out + t,s (written) — 391 MB at B=256, L=512, n=120 against 880 MB for the
+// three-launch form.
+//
+// Structure (shared with conv_gemm_bf3_kernel): split-bf16 products — hi·hi + hi·lo + lo·hi on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulation — operands through a 3-slot LDS ring filled by LDS-DMA, one raw
+// s_barrier per 16-deep stage behind a counted vmcnt.  A workgroup = 4 waves = one batch element × 128 time samples;
+// every wave owns ALL 256 (padded) output rows of its 32 samples, so that
+//   * row m (tanh half) and row m+128 (sigmoid half) of GEMM 1 sit in the same lane and register index (blocks b and b+4):
+//     the gate is pure per-lane VALU work on the accumulators;
+//   * the 32×32 accumulator tiles of acts are, register for register, the B operand of GEMM 2 (a following MFMA that
+//     sums over the accumulator's ROW index takes it with no lane movement: cdna_hip_programming.md §3) — the weights
+//     of GEMM 2 are packed in the k-order that layout implies (wn_pack_kernel).
+// Biases ride in the GEMMs: GEMM 1 has a constant-one input row (the first padding channel of the conditioning
+// chunk, fed from a 16-byte block of ones), GEMM 2 sees acts[n] = 1 — so n < 128 is required (one spare K row).
+// Two workgroups share a CU (79 KB of LDS, ≤ 256 registers): one's t,s store burst is the other's MFMA time.
+#include "fst_common.h"
+
+typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float wn_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wn_u32x4 __attribute__((ext_vector_type(4)));
+#define WN_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define WN_LDS_VOID(p) ((__attribute__((address_space(3))) void*)(p))
+
+#define WN_TN 128                                  // time samples per workgroup
+#define WN_NBLK (WN_TN / 32 + 1)                   // 32-sample column blocks per 8-channel row group (+1: sub-shift spill)
+#define WN_GS (WN_NBLK * 1024 + 128)               // bytes per 8-channel row group (+128: the lane halves hit different banks)
+#define WN_A_BYTES (8 * 2048)                      // 8 row blocks × (1 KiB hi + 1 KiB lo fragments)
+#define WN_SLOT (WN_A_BYTES + 2 * WN_GS)
+#define WN_TILE_BYTES (32 * 36 * 4)                // one wave's [32][36] fp32 transpose tile
+#define WN_LDS_BYTES (3 * WN_SLOT)
+
+__device__ __forceinline__ void wn_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const wn_f32x2 v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, wn_bf16x2));
+  const wn_f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wn_bf16x2));
+}
+
+template <int N>
+__device__ __forceinline__ void wn_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// sigmoid and tanh from v_exp_f32 / v_rcp_f32 (≈1 ulp each): absolute error ≈ 2e-7, saturating correctly at ±inf
+__device__ __forceinline__ float wn_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x));
+}
+__device__ __forceinline__ float wn_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * x));
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight image
+//   [S1 stages of GEMM 1][8 k-steps of GEMM 2][16 B of zeros][16 B of ones]
+// one stage / k-step = 8 row blocks × (64 lanes × 8 bf16 hi, 64 lanes × 8 bf16 lo) = 16 KiB, the A fragments of
+// v_mfma_f32_32x32x16_bf16 (lane l: row l&31 of the block, k = 8·(l>>5) + j).
+//   GEMM 1  stage (tap, c) = tap·CH + c, c < CH = ⌈n/16⌉: channels 16c.. of `a` at tap `tap`; then CH2 = ⌈(h+1)/16⌉ stages
+//           of the conditioning input (zero shift) whose channel h is the constant-one row carrying b_in + b_cond.
+//           rows: blocks 0-3 = tanh rows 0..n-1, blocks 4-7 = sigmoid rows n..2n-1.
+//   GEMM 2  k-step ks = (blk, s): element j of lane half hh multiplies acts row blk·32 + 16s + 8(j>>2) + 4hh + (j&3)
+//           (the order in which an accumulator tile delivers its rows as a B operand); k = n carries b_rs.
+//           rows: blocks 0-3 = residual rows (→ a_next), blocks 4-7 = skip rows (→ out); last layer: only skip rows.
+// ------------------------------------------------------------------------------------------------
+struct WnPackParams {
+  const float* in_w;    // [2n][n][3]
+  const float* cond_w;  // [2n][h]
+  const float* in_b;    // [2n]
+  const float* cond_b;  // [2n]
+  const float* rs_w;    // [2n][n]  (last: [n][n])
+  const float* rs_b;    // [2n]     (last: [n])
+  int n, h, last, CH, CH2;
+  uint4* img;
+};
+
+__global__ __launch_bounds__(64) void wn_pack_kernel(WnPackParams p) {
+  const int lane = threadIdx.x, blk = blockIdx.x & 7, st = blockIdx.x >> 3;
+  const int S1 = 3 * p.CH + p.CH2, n = p.n, h = p.h;
+  const int hh = lane >> 5, rowb = (blk & 3) * 32 + (lane & 31);
+  const bool row_ok = rowb < n;
+  float v[8];
+  if (st < S1) {
+    const int row = (blk < 4 ? 0 : n) + rowb;                       // tanh | sigmoid half of the in_layer / cond_layer
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float w = 0.f;
+      if (row_ok) {
+        if (st < 3 * p.CH) {
+          const int tap = st / p.CH, c = (st - tap * p.CH) * 16 + 8 * hh + j;
+          if (c < n) w = p.in_w[((long long)row * n + c) * 3 + tap];
+        } else {
+          const int c = (st - 3 * p.CH) * 16 + 8 * hh + j;
+          if (c < h) w = p.cond_w[(long long)row * h + c];
+          else if (c == h) w = p.in_b[row] + p.cond_b[row];
+        }
+      }
+      v[j] = w;
+    }
+  } else {
+    const int ks = st - S1, kb = ks >> 1, s = ks & 1;
+    const bool skip = blk >= 4;
+    const bool live = row_ok && (!p.last || skip);
+    const int row = (skip && !p.last ? n : 0) + rowb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kb * 32 + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+      float w = 0.f;
+      if (live) {
+        if (k < n) w = p.rs_w[(long long)row * n + k];
+        else if (k == n) w = p.rs_b[row];
+      }
+      v[j] = w;
+    }
+  }
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wn_split_pair(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+  uint4* dst = p.img + ((long long)st * 8 + blk) * 128 + lane;
+  dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  dst[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  if (blockIdx.x == 0 && lane < 2) {
+    const unsigned one = lane ? 0x3f800000u : 0u;
+    p.img[(long long)(S1 + 8) * 8 * 128 + lane] = make_uint4(one, one, one, one);
+  }
+}
+
+static inline int wn_ch(int n) { return (n + 15) / 16; }
+static inline int wn_ch2(int h) { return (h + 1 + 15) / 16; }
+
+extern "C" int64_t fst_wn_image_bytes(int n, int h) {
+  if (n <= 0 || h <= 0) return -1;
+  return (int64_t)(3 * wn_ch(n) + wn_ch2(h) + 8) * WN_A_BYTES + 32;
+}
+
+extern "C" int fst_wn_pack(const float* in_w, const float* cond_w, const float* in_b, const float* cond_b,
+                           const float* rs_w, const float* rs_b, int n, int h, int last, void* image,
+                           int64_t image_bytes, void* stream) {
+  FST_REQUIRE(in_w && cond_w && in_b && cond_b && rs_w && rs_b && image, "fst_wn_pack: null operand");
+  FST_REQUIRE(n > 0 && n < 128 && h > 0, "fst_wn_pack: needs 0 < n < 128 (one spare K row carries the bias), h > 0; n=%d h=%d", n, h);
+  FST_REQUIRE(image_bytes == fst_wn_image_bytes(n, h), "fst_wn_pack: image is %lld bytes, expected %lld",
+              (long long)image_bytes, (long long)fst_wn_image_bytes(n, h));
+  FST_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, "fst_wn_pack: image must be 16-byte aligned");
+  WnPackParams p = {in_w, cond_w, in_b, cond_b, rs_w, rs_b, n, h, last ? 1 : 0, wn_ch(n), wn_ch2(h), static_cast<uint4*>(image)};
+  const int stages = 3 * p.CH + p.CH2 + 8;
+  hipLaunchKernelGGL(wn_pack_kernel, dim3((unsigned)(stages * 8)), dim3(64), 0, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward layer
+// ------------------------------------------------------------------------------------------------
+struct WnFwdParams {
+  const float* a;
+  long long a_bs;
+  const float* u0;
+  long long u0_bs;
+  const char* img;
+  float* ts;       // [B][2n][L]
+  float* acts;     // [B][n][L] or null
+  float* a_next;   // [B][n][L] (null on the last layer)
+  float* out;      // [B][n][L]
+  int B, L, n, h, dil, first, last;
+  int CH, CH2, tiles_per_seq, n_wg;
+};
+
+// One accumulator tile (lane = time sample, registers = rows) → wave-private LDS tile [32][36] → each lane owns 4
+// consecutive samples of rows rrow + 8j: four 16-byte global accesses per 32×32 tile, 8 rows × 128 contiguous bytes
+// per wave-instruction.  MODE 0: store; 1: dst = v + res; 2: dst += v.
+template <int MODE>
+__device__ __forceinline__ void wn_store_tile(const float (&v)[16], float* tile, float* dst_rows, const float* res_rows,
+                                              int rows_valid, int L, int t, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = v[r];
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  const bool t_ok = t + c4 < L;
+  float4 o[4], e[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = rrow + 8 * j;
+    o[j] = *reinterpret_cast<const float4*>(tile + row * 36 + c4);
+    e[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE != 0 && t_ok && row < rows_valid) {
+      const float* src = (MODE == 1 ? res_rows : dst_rows) + (long long)row * L + t + c4;
+      e[j] = *reinterpret_cast<const float4*>(src);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = rrow + 8 * j;
+    if (t_ok && row < rows_valid) {
+      float4 w = o[j];
+      w.x += e[j].x; w.y += e[j].y; w.z += e[j].z; w.w += e[j].w;
+      *reinterpret_cast<float4*>(dst_rows + (long long)row * L + t + c4) = w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NA = WN_A_BYTES / 1024;              // 16 one-KiB pieces of A per stage
+  constexpr int NI1 = NA + 2 * WN_NBLK;              // 26 LDS-DMA wave-instructions per GEMM-1 stage
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Workgroup → tile: ids that differ by a multiple of 8 share an XCD (round-robin dispatch), so give each XCD a
+  // contiguous run of tiles: the tiles of one sequence, which re-read each other's halo for the dilated taps, then
+  // meet in one L2.  Speed only.
+  int wg = blockIdx.x;
+  if ((p.n_wg & 7) == 0) wg = (wg & 7) * (p.n_wg >> 3) + (wg >> 3);
+  const int b = wg / p.tiles_per_seq;
+  const int t0 = (wg - b * p.tiles_per_seq) * WN_TN;
+  const int wave_n0 = wave_s * 32;
+  const int L = p.L, n = p.n, h = p.h, CH = p.CH;
+  const int S1 = 3 * CH + p.CH2;
+  const char* const zero16 = p.img + (long long)(S1 + 8) * WN_A_BYTES;
+  const char* const ones16 = zero16 + 16;
+  const float* const ab = p.a + (long long)b * p.a_bs;
+  const float* const ub = p.u0 + (long long)b * p.u0_bs;
+
+  // LDS-DMA of stage k into ring slot `slot`.  GEMM-1 stages: pieces [0, NA) are A, the rest the B sub-tiles
+  // (8 channels × 32 samples of the 16-byte aligned, tap-shifted window); GEMM-2 k-steps: A only.
+  auto issue = [&](int k, int slot) {
+    char* const sl = ldsb + slot * WN_SLOT;
+    const char* asrc = p.img + (long long)k * WN_A_BYTES;
+    if (k >= S1) {
+      const int a0 = p.last ? 8 : 0;                 // last layer: only the skip-row blocks exist
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = a0 + wave_s + 4 * i;
+        if (idx < NA)
+          __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+      }
+      return;
+    }
+    const float* xb;
+    int c_count, ones_row, shift;
+    if (k < 3 * CH) {
+      const int tap = k / CH, c = k - tap * CH;
+      xb = ab + (long long)(16 * c) * L;
+      c_count = min(16, n - 16 * c);
+      ones_row = -1;
+      shift = (tap - 1) * p.dil;
+    } else {
+      const int c = k - 3 * CH;
+      xb = ub + (long long)(16 * c) * L;
+      c_count = min(16, h - 16 * c);
+      ones_row = h - 16 * c;                         // in [0, 16) on exactly one conditioning stage
+      shift = 0;
+    }
+    const int tbase = t0 + shift;
+    const int t4 = tbase & ~3;
+    const bool spill = (tbase & 3) != 0;
+#pragma unroll
+    for (int i = 0; i < (NI1 + 3) / 4; ++i) {
+      const int idx = wave_s + 4 * i;
+      if (idx >= NI1) break;                         // wave-uniform
+      if (idx < NA) {
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+      } else {
+        const int bi = idx - NA;
+        const int gq = bi >= WN_NBLK ? 1 : 0, m = bi - gq * WN_NBLK;
+        const int row = 8 * gq + (lane >> 3);
+        const int t = t4 + 32 * m + 4 * (lane & 7);
+        bool ok = row < c_count && t >= 0 && t < L;
+        if (m == WN_NBLK - 1) ok = ok && spill && (lane & 7) == 0;
+        const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : (row == ones_row ? ones16 : zero16);
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_A_BYTES + gq * WN_GS + m * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // wait until this wave's pieces of the stage about to be read have landed; `next` = the one stage issued after it
+  auto wait_for = [&](int next, int S) {
+    if (next >= S) wn_wait_vmcnt<0>();
+    else if (next < S1) { if (wave_s < (NI1 & 3)) wn_wait_vmcnt<(NI1 + 3) / 4>(); else wn_wait_vmcnt<NI1 / 4>(); }
+    else if (p.last) wn_wait_vmcnt<2>();
+    else wn_wait_vmcnt<4>();
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+  const int S = S1 + 8;
+  issue(0, 0);
+  issue(1, 1);
+  int slot = 0;
+  // ---------------------------------------------------------------- GEMM 1: g = [W_in | W_cond | b] · [a taps ; u0 ; 1]
+  for (int k = 0; k < S1; ++k) {
+    wait_for(k + 1, S);
+    __builtin_amdgcn_s_barrier();                      // stage k is in LDS for everyone; the slot refilled next is drained
+    issue(k + 2, slot >= 1 ? slot - 1 : 2);            // (k + 2 < S always holds here: 8 k-steps of GEMM 2 follow)
+    int shift = 0;
+    if (k < 3 * CH) shift = (k / CH - 1) * p.dil;
+    const int sub = (t0 + shift) & 3;
+    const char* base = ldsb + slot * WN_SLOT;
+    const int colx = wave_n0 + l31 + sub;
+    const char* bp = base + WN_A_BYTES + half * WN_GS + (colx >> 5) * 1024 + (colx & 31) * 4;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
+    wn_u32x4 bh4, bl4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned hh, ll;
+      wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
+      bh4[j] = hh; bl4[j] = ll;
+    }
+    const wn_bf16x8 bh = __builtin_bit_cast(wn_bf16x8, bh4), bl = __builtin_bit_cast(wn_bf16x8, bl4);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
+      const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+  // ---------------------------------------------------------------- gate (between stage S1-1 and the first k-step of GEMM 2)
+  // Drain: the two k-steps in flight (S1, S1+1: A only, L2 hits issued one and two stages ago) land, so from here on
+  // the t,s stores below are OLDER than every LDS-DMA a counted vmcnt will wait for — a counted wait retires
+  // everything older than what it waits for, i.e. the stores get two k-steps of MFMA time to complete before the wait
+  // in front of k-step S1+2 can see them.
+  wn_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();                        // every wave is past its last B read: the B areas are free
+  // wave-private transpose tile inside the (now dead) B area of ring slot wave/2
+  float* const tile = reinterpret_cast<float*>(ldsb + (wave_s >> 1) * WN_SLOT + WN_A_BYTES + (wave_s & 1) * WN_TILE_BYTES);
+  const int tcol = t0 + wave_n0;
+  float* const ts_b = p.ts + (long long)b * (2 * n) * L;
+  wn_bf16x8 bh2[8], bl2[8];
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    float tv[16], sv[16], av[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float gt = acc[blk][r], gs = acc[blk + 4][r];
+      tv[r] = wn_tanh(gt);
+      sv[r] = wn_sigmoid(gs);
+      const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      av[r] = row == n ? 1.0f : tv[r] * sv[r];         // acts[n] = 1 carries b_rs through GEMM 2 (rows > n: tanh(0)·σ(0) = 0)
+    }
+    const int rows_valid = n - blk * 32;               // may be <= 0: nothing stored
+    wn_store_tile<0>(tv, tile, ts_b + (long long)(blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+    wn_store_tile<0>(sv, tile, ts_b + (long long)(n + blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+    if (p.acts) {
+      float aw[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) aw[r] = tv[r] * sv[r];
+      wn_store_tile<0>(aw, tile, p.acts + ((long long)b * n + blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      wn_u32x4 h4, l4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned hh, ll;
+        wn_split_pair(av[8 * s + 2 * j], av[8 * s + 2 * j + 1], hh, ll);
+        h4[j] = hh; l4[j] = ll;
+      }
+      bh2[2 * blk + s] = __builtin_bit_cast(wn_bf16x8, h4);
+      bl2[2 * blk + s] = __builtin_bit_cast(wn_bf16x8, l4);
+    }
+  }
+  asm volatile("" ::: "memory");                       // the stores stay in front of the LDS-DMA issued below
+
+  // ---------------------------------------------------------------- GEMM 2: r = [W_rs | b] · [acts ; 1]
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int k = S1 + ks;
+    if (ks >= 2) wait_for(k + 1, S);                   // k-steps S1 and S1+1 landed at the drain above
+    if (ks >= 1) __builtin_amdgcn_s_barrier();
+    if (k + 2 < S) issue(k + 2, slot >= 1 ? slot - 1 : 2);
+    const char* base = ldsb + slot * WN_SLOT;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      if (p.last && mb < 4) continue;                  // wave-uniform
+      const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
+      const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh2[ks], acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2[ks], acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh2[ks], acc[mb], 0, 0, 0);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+  // ---------------------------------------------------------------- a_next = a + r[:n];  out (+)= r[n:]
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const int rows_valid = n - blk * 32;
+    float v[16];
+    if (!p.last) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[blk][r];
+      wn_store_tile<1>(v, tile, p.a_next + ((long long)b * n + blk * 32) * L, ab + (long long)(blk * 32) * L, rows_valid, L,
+                       tcol, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[blk + 4][r];
+    float* orow = p.out + ((long long)b * n + blk * 32) * L;
+    if (p.first) wn_store_tile<0>(v, tile, orow, nullptr, rows_valid, L, tcol, lane);
+    else wn_store_tile<2>(v, tile, orow, nullptr, rows_valid, L, tcol, lane);
+  }
+}
+
+extern "C" int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, int64_t u0_bs, const void* image,
+                                int64_t image_bytes, float* ts, float* acts, float* a_next, float* out, int first, int last,
+                                int B, int L, int n, int h, int dil, int64_t numel_a, void* stream) {
+  FST_REQUIRE(a && u0 && image && ts && out && (last || a_next), "fst_wn_layer_fwd: null operand");
+  FST_REQUIRE(B > 0 && L > 0 && n > 0 && n < 128 && h > 0 && dil > 0, "fst_wn_layer_fwd: B=%d L=%d n=%d h=%d dil=%d (needs n < 128)",
+              B, L, n, h, dil);
+  FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_layer_fwd: B*n*L = %d*%d*%d does not match the element count %lld "
+              "of the [B, n, L] tensors", B, n, L, (long long)numel_a);
+  FST_REQUIRE(image_bytes == fst_wn_image_bytes(n, h), "fst_wn_layer_fwd: image is %lld bytes, expected %lld",
+              (long long)image_bytes, (long long)fst_wn_image_bytes(n, h));
+  FST_REQUIRE(B == 1 || (a_bs >= (int64_t)n * L && u0_bs >= (int64_t)h * L), "fst_wn_layer_fwd: batch stride smaller than a sample");
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  FST_REQUIRE(L % 4 == 0 && a_bs % 4 == 0 && u0_bs % 4 == 0 && al16(a) && al16(u0) && al16(image) && al16(ts) && al16(acts) &&
+              al16(a_next) && al16(out), "fst_wn_layer_fwd: needs L %% 4 == 0 and 16-byte aligned tensors (L=%d)", L);
+  WnFwdParams p;
+  p.a = a; p.a_bs = a_bs; p.u0 = u0; p.u0_bs = u0_bs; p.img = static_cast<const char*>(image);
+  p.ts = ts; p.acts = acts; p.a_next = a_next; p.out = out;
+  p.B = B; p.L = L; p.n = n; p.h = h; p.dil = dil; p.first = first ? 1 : 0; p.last = last ? 1 : 0;
+  p.CH = wn_ch(n); p.CH2 = wn_ch2(h);
+  p.tiles_per_seq = (L + WN_TN - 1) / WN_TN;
+  p.n_wg = B * p.tiles_per_seq;
+  if (int rc = fst_allow_full_lds((const void*)wn_layer_fwd_kernel, "fst_wn_layer_fwd")) return rc;
+  hipLaunchKernelGGL(wn_layer_fwd_kernel, dim3((unsigned)p.n_wg), dim3(256), WN_LDS_BYTES, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}

@@ -656,6 +656,52 @@ class WNSpecs:
         self.rs_T_last = build_plan(n, [Segment(0, n, 0, 1)], 1, 1, 0, chunk_c=PIPE_C)
 
 
+def wn_fused_ok(n: int, h: int, L: int, *tensors: Tensor) -> bool:
+    """Whether a WN layer takes the fused one-launch-per-layer kernels (csrc/wn_fused.hip): split-bf16 arithmetic,
+    n < 128 (one spare K row carries the biases), 16-byte aligned rows."""
+    if MATH != "bf16x3" or not (0 < n < 128) or L % 4 != 0 or os.environ.get("FST_WN_FUSED", "1") == "0":
+        return False
+    return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 for t in tensors)
+
+
+def wn_pack_layer(in_w: Tensor, cond_w: Tensor, in_b: Tensor, cond_b: Tensor, rs_w: Tensor, rs_b: Tensor, n: int, h: int,
+                  last: bool) -> Tensor:
+    """One layer's weight image for the fused kernels (cached for the step like every packed weight)."""
+    lib = _lib.load()
+    key = None
+    if _PACK_CACHE is not None:
+        key = ("wn", n, h, last) + tuple((t.data_ptr(), t._version) for t in (in_w, cond_w, in_b, cond_b, rs_w, rs_b))
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            return hit[0]
+    nbytes = lib.fst_wn_image_bytes(n, h)
+    img = torch.empty(nbytes // 4, device=in_w.device, dtype=torch.float32)
+    src = [t.contiguous() for t in (in_w, cond_w, in_b, cond_b, rs_w, rs_b)]
+    check(lib.fst_wn_pack(*[ptr(t) for t in src], n, h, int(last), ptr(img), nbytes, stream_ptr()), "fst_wn_pack")
+    if key is not None:
+        _PACK_CACHE[key] = (img, in_w, cond_w, in_b, cond_b, rs_w, rs_b, src)
+    return img
+
+
+def wn_layer_fwd(a: Tensor, u0: Tensor, img: Tensor, ts: Tensor, acts: Optional[Tensor], a_next: Optional[Tensor], out: Tensor,
+                 first: bool, last: bool, n: int, h: int, dil: int) -> None:
+    lib = _lib.load()
+    a_bs, L = _ncl(a, "a")
+    u0_bs, _ = _ncl(u0, "u0")
+    B = a.size(0)
+    numel = _same_numel(a, out, acts, a_next)
+    if ts.numel() != 2 * numel or not ts.is_contiguous():
+        raise ValueError("wn_layer_fwd: ts must be the contiguous [B, 2n, L] partner of a")
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_wn_layer_fwd(ptr(a), a_bs, ptr(u0), u0_bs, ptr(img), img.numel() * 4, ptr(ts), ptr(acts), ptr(a_next), ptr(out),
+                               int(first), int(last), B, L, n, h, dil, numel, stream_ptr()), "fst_wn_layer_fwd")
+    if t0 is not None:
+        rs_rows = n if last else 2 * n
+        flops = 2.0 * B * L * (2 * n * (3 * n + h) + rs_rows * n)
+        rows = n + h + (0 if first else n) + (0 if last else n) + n + 2 * n + (n if acts is not None else 0)
+        KERNEL_TIMER.end("wn_layer_fwd_kernel", t0, flops, 4.0 * B * L * rows)
+
+
 class WNFn(torch.autograd.Function):
     """The whole gated dilated-conv stack (:101-123) as one autograd node.
 
@@ -677,10 +723,28 @@ class WNFn(torch.autograd.Function):
         B, _, L = u0.shape
         h, n = S.h, S.n
         a = S.start.forward(u0, None, start_w, None, start_b)
-        out = torch.zeros(B, n, L, device=u0.device, dtype=torch.float32)
         a_list, ts_list, acts_list = [a], [], []
-        bias_g = torch.stack(list(in_b)) + cond_b.view(nl, 2 * n)
-        for i in range(nl):
+        fused = wn_fused_ok(n, h, L, a, u0)
+        if fused:
+            # one launch per layer: dilated conv + cond rows → gate in registers → res_skip → residual / skip adds
+            out = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
+            cb = cond_b.view(nl, 2 * n)
+            for i in range(nl):
+                last = i == nl - 1
+                img = wn_pack_layer(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], in_b[i], cb[i], rs_w[i], rs_b[i], n, h, last)
+                ts = torch.empty(B, 2 * n, L, device=u0.device, dtype=torch.float32)
+                acts = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
+                a_next = None if last else torch.empty_like(a)
+                wn_layer_fwd(a, u0, img, ts, acts, a_next, out, i == 0, last, n, h, 2 ** i)
+                ts_list.append(ts)
+                acts_list.append(acts)
+                if not last:
+                    a = a_next
+                    a_list.append(a)
+        else:
+            out = torch.zeros(B, n, L, device=u0.device, dtype=torch.float32)
+            bias_g = torch.stack(list(in_b)) + cond_b.view(nl, 2 * n)
+        for i in range(0 if fused else nl):
             g = S.ins[i].forward(a, u0, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], bias_g[i])
             acts = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
             check(lib.fst_gate_fwd(ptr(g), ptr(acts), B, n, L, _gate_numel(acts, g), stream_ptr()), "fst_gate_fwd")

@@ -165,6 +165,28 @@ int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h
 int fst_coupling_inv_bwd(const float* xn, const float* o, const float* dxn,
                          float* dx, float* d_o, int B, int h, int L, int64_t numel, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused WN layer (Simplified_NF_WaveGlow.py:101-123 with the gate of :44-54): ONE launch per layer
+ *   g = in_layer(a) + cond_layer(u0)[2n·i : 2n·(i+1)]  →  t = tanh(g[:n]), s = sigmoid(g[n:]), acts = t·s
+ *   r = res_skip_layer(acts);  a_next = a + r[:n];  out (+)= r[n:]        (last layer: r has n rows, out += r)
+ * on the split-bf16 matrix cores; the [B, 2n, L] pre-activation stays in registers.  Needs n < 128 (one spare K row
+ * carries the biases through the GEMMs), L % 4 == 0 and 16-byte aligned tensors.
+ *   fst_wn_image_bytes(n, h)   size of one layer's packed weight image
+ *   fst_wn_pack                effective (weight-norm folded) weights of one layer → image.  in_w [2n][n][3],
+ *                              cond_w [2n][h] (this layer's rows of cond_layer), in_b / cond_b [2n],
+ *                              rs_w [2n][n] and rs_b [2n]  (last layer: [n][n], [n])
+ *   fst_wn_layer_fwd           a [B][n][L] (batch stride a_bs), u0 [B][h][L] (batch stride u0_bs: a channel slice of a wider
+ *                              tensor passes without a copy), ts [B][2n][L] ← (t | s) kept for backward, acts [B][n][L] or NULL,
+ *                              a_next [B][n][L] (NULL iff last), out [B][n][L] (written if first, else accumulated);
+ *                              numel_a = element count of the [B][n][L] tensors as the caller holds them.
+ * ------------------------------------------------------------------------------------------- */
+int64_t fst_wn_image_bytes(int n, int h);
+int fst_wn_pack(const float* in_w, const float* cond_w, const float* in_b, const float* cond_b,
+                const float* rs_w, const float* rs_b, int n, int h, int last, void* image, int64_t image_bytes, void* stream);
+int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, int64_t u0_bs, const void* image, int64_t image_bytes,
+                     float* ts, float* acts, float* a_next, float* out, int first, int last,
+                     int B, int L, int n, int h, int dil, int64_t numel_a, void* stream);
+
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */
 int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,

@@ -53,7 +53,23 @@ def _step_both(js, tr, batch, ts):
     return rep_o, want, rep, grads
 
 
-def _check_step(rep_o, want, rep, grads, tr, what, grad_tol=2e-3):
+# Gradient tolerances (of each module's gradient scale).  f32 MFMA mode: 1e-3 everywhere (measured 1e-4 and better).
+# Split-bf16 mode: 2e-3, EXCEPT the feature extractors: the weight gradient of a conv in front of a train-mode BatchNorm
+# is a sum over (b, t) of dy·x with dy orthogonal to both 1 and x-hat — at L = 512 it cancels to ~1/600 of Σ|dy·x| (the
+# exact-f32 path itself measures 4e-5 = 600 fp32 epsilons there), so the 4e-6 per-product error of the three-MFMA split
+# shows as 2.6e-3 of the gradient scale (tools/grad_diag.py).  6e-3 leaves a factor two.
+GRAD_TOL = {"f32": {"default": 1e-3}, "bf16x3": {"default": 2e-3, "fe_t": 6e-3, "fe_s": 6e-3}}
+
+
+@pytest.fixture(params=["bf16x3", "f32"])
+def arithmetic(request):
+    from feature_level_style_transfer_for_tsc_amd import ops
+    prev, ops.MATH = ops.MATH, request.param
+    yield request.param
+    ops.MATH = prev
+
+
+def _check_step(rep_o, want, rep, grads, tr, what, math="bf16x3"):
     for k in LOSSES:
         a, b = float(rep[k]), float(rep_o[k])
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (what, k, a, b)
@@ -64,20 +80,20 @@ def _check_step(rep_o, want, rep, grads, tr, what, grad_tol=2e-3):
     close(rep["norms_s"], rep_o["norms_s"], 1e-3, f"{what} GradNorm norms_s")
     close(rep["w_t"], rep_o["w_t"], 1e-4, f"{what} w_t")
     close(rep["w_s"], rep_o["w_s"], 1e-4, f"{what} w_s")
+    tol = GRAD_TOL[math]
     for name in tr.MODULES:
-        assert set(want[name]) == set(grads[name]), (what, name, set(want[name]) ^ set(grads[name]))
-        check_grads(tr.m[name], want[name], grad_tol, f"{what} Q3 {name} ", grads=grads[name])
+        check_grads(tr.m[name], want[name], tol.get(name, tol["default"]), f"{what} Q3 {name} ", grads=grads[name])
 
 
 @pytest.mark.parametrize("L,B,seed", [(512, 4, 512), (1024, 2, 1024)])
-def test_whole_joint_step_with_gradients_vs_oracle(L, B, seed):
+def test_whole_joint_step_with_gradients_vs_oracle(L, B, seed, arithmetic):
     """configs[1] (L=512) and configs[4] (L=1024) geometry: forward, GradNorm and the accumulated gradients of the
     whole step, all eleven modules, against the oracle from identical seeded state."""
     js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=seed, dropout_p=0.0, zero_end=False)
     tr = _trainer_from(js, L, L, 4)
     gen = torch.Generator().manual_seed(seed + 1)
     batch = (_pair(gen, B, 1, L, 4), _pair(gen, B, 1, L, 4))
-    _check_step(*_step_both(js, tr, batch, (L // 8, L // 16)), tr, f"L={L}")
+    _check_step(*_step_both(js, tr, batch, (L // 8, L // 16)), tr, f"L={L} {arithmetic}", math=arithmetic)
 
 
 def test_config2_four_sources_one_step_each_then_vote():
@@ -97,7 +113,7 @@ def test_config2_four_sources_one_step_each_then_vote():
         js = R.build_joint_step(L, 1, L, 1, ncls, ncls, seed=100 + k, dropout_p=0.0, zero_end=False)
         tr = _trainer_from(js, L, L, ncls)
         batch = (target, _pair(gen, B, 1, L, ncls))
-        _check_step(*_step_both(js, tr, batch, (17 + k, 40 - k)), tr, f"source {k}", grad_tol=2e-3)
+        _check_step(*_step_both(js, tr, batch, (17 + k, 40 - k)), tr, f"source {k}")
         fe, clf = tr.m["fe_t"], tr.m["clf_t"]
         fe.eval(); clf.eval()
         models.append((fe, clf))

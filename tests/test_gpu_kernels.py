@@ -364,3 +364,49 @@ def test_batch_norm_global_batch_arguments_stay_inside_their_buffers():
     assert rc < 0
     torch.cuda.synchronize()
     assert bool((dxbuf[:PAD] == CANARY).all()) and bool((dxbuf[PAD + n:] == CANARY).all())
+
+
+@pytest.mark.parametrize("n,h,B,L,dil,first,last", [
+    (120, 25, 2, 512, 1, True, False), (120, 25, 2, 512, 8, False, False), (120, 25, 3, 512, 128, False, False),
+    (120, 25, 2, 512, 128, False, True), (120, 25, 2, 200, 4, False, False),      # partial last tile (200 = 128 + 72)
+    (8, 3, 3, 40, 2, False, False), (8, 3, 2, 40, 1, True, True), (127, 16, 1, 256, 16, False, False), (33, 31, 2, 132, 64, False, False)])
+def test_fused_wn_layer_forward(n, h, B, L, dil, first, last):
+    """fst_wn_layer_fwd (dilated conv + cond rows + bias -> gate -> res_skip + bias -> residual / skip adds in ONE launch)
+    against fp64 torch; the saved gate halves and acts too."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n * 1000 + L + dil)
+    rnd = lambda *s, k=1.0: torch.randn(*s, generator=g, dtype=torch.float64) * k
+    a, u0full = rnd(B, n, L), rnd(B, 2 * h, L)
+    u0 = u0full[:, :h]                                                     # a channel-slice view, as WaveGlow passes it
+    in_w, cond_w = rnd(2 * n, n, 3, k=(3 * n) ** -0.5), rnd(2 * n, h, 1, k=h ** -0.5)
+    in_b, cond_b = rnd(2 * n, k=0.3), rnd(2 * n, k=0.3)
+    R = n if last else 2 * n
+    rs_w, rs_b = rnd(R, n, 1, k=n ** -0.5), rnd(R, k=0.3)
+    out0 = rnd(B, n, L)
+    gg = F.conv1d(a, in_w, in_b, dilation=dil, padding=dil) + F.conv1d(u0, cond_w, cond_b)
+    t, s = torch.tanh(gg[:, :n]), torch.sigmoid(gg[:, n:])
+    acts = t * s
+    r = F.conv1d(acts, rs_w, rs_b)
+    a_next = None if last else a + r[:, :n]
+    out = (0 if first else out0) + (r if last else r[:, n:])
+    f = lambda x: x.float().to(DEV).contiguous()
+    ad, u0d = f(a), f(u0full)[:, :h]
+    img = ops.wn_pack_layer(f(in_w), f(cond_w), f(in_b), f(cond_b), f(rs_w), f(rs_b), n, h, last)
+    ts_d, acts_d = torch.full((B, 2 * n, L), 7.0, device=DEV), torch.full((B, n, L), 7.0, device=DEV)
+    an_d = None if last else torch.full((B, n, L), 7.0, device=DEV)
+    out_d = torch.full((B, n, L), 7.0, device=DEV) if first else f(out0)
+    assert ops.wn_fused_ok(n, h, L, ad, u0d)
+    ops.wn_layer_fwd(ad, u0d, img, ts_d, acts_d, an_d, out_d, first, last, n, h, dil)
+    # the gate halves inherit the GEMM's error (split-bf16: ~5e-6 of the pre-activation scale) through tanh' <= 1
+    gtol = 1e-5 * float(gg.abs().max())
+    assert_close(ts_d[:, :n], t, gtol, "t")
+    assert_close(ts_d[:, n:], s, gtol, "s")
+    assert_close(acts_d, acts, gtol, "acts")
+    if not last:
+        assert_close(an_d, a_next, 2e-5, "a_next")
+    assert_close(out_d, out, 2e-5, "out")
+    # and without the optional acts output
+    ts2, out2 = torch.empty_like(ts_d), (torch.empty_like(out_d) if first else f(out0))
+    an2 = None if last else torch.empty_like(an_d)
+    ops.wn_layer_fwd(ad, u0d, img, ts2, None, an2, out2, first, last, n, h, dil)
+    assert torch.equal(ts2, ts_d) and torch.equal(out2, out_d)

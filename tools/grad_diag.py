@@ -1,0 +1,33 @@
+"""Diagnostic: whole joint step vs the oracle — per-parameter gradient error (max |err| / module scale, relative L2).
+usage: python tools/grad_diag.py [L] [B] [seed]   (FST_MATH=f32|bf16x3 picks the arithmetic)"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import feature_level_style_transfer_for_tsc_amd as fst
+from feature_level_style_transfer_for_tsc_amd import ops
+from oracle import restatement as R
+from test_gpu_full_step import _pair, _trainer_from, _step_both
+
+L, B, seed = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 512), (2, 4), (3, 512)))
+js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=seed, dropout_p=0.0, zero_end=False)
+tr = _trainer_from(js, L, L, 4)
+gen = torch.Generator().manual_seed(seed + 1)
+batch = (_pair(gen, B, 1, L, 4), _pair(gen, B, 1, L, 4))
+rep_o, want, rep, grads = _step_both(js, tr, batch, (L // 8, L // 16))
+print("MATH", ops.MATH)
+for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s"):
+    print(f"  loss {k:9s} {float(rep[k]):+.6e} oracle {float(rep_o[k]):+.6e} rel {abs(float(rep[k]) - float(rep_o[k])) / max(1, abs(float(rep_o[k]))):.1e}")
+for name in tr.MODULES:
+    scale = max(float(np.abs(v).max()) for v in want[name].values())
+    worst = []
+    for k, v in want[name].items():
+        g = grads[name][k].detach().cpu().numpy()
+        err = float(np.abs(g - v).max())
+        l2 = float(np.linalg.norm(g - v) / max(1e-30, np.linalg.norm(v)))
+        worst.append((err / scale, l2, k))
+    worst.sort(reverse=True)
+    print(f"{name:13s} scale {scale:.3e}  worst: " + "; ".join(f"{k} {e:.1e} (L2 {l:.1e})" for e, l, k in worst[:3]))
