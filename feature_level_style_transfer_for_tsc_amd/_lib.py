@@ -57,6 +57,9 @@ _SIGNATURES = {
     "fst_wn_pack": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_void_p]),
     "fst_wn_layer_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int64, c_void_p]),
+    "fst_wn_bwd_image_bytes": (c_int64, [c_int, c_int]),
+    "fst_wn_pack_bwd": (c_int, [_P, c_int, c_int, _P, c_int64, c_void_p]),
+    "fst_wn_layer_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_axpy": (c_int, [_P, _P, c_float, c_int64, c_void_p]),
     "fst_add_slices": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_void_p]),
     "fst_cpc_nce_fwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_void_p]),

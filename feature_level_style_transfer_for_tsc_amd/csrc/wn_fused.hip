@@ -450,3 +450,222 @@ extern "C" int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, i
   FST_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// backward through res_skip and the gate:  dacts = W_rsᵀ·[d_a_next ; d_out],  dg = gate'(t, s)·dacts
+//
+// GEMM 3 has M = n (4 row blocks), K = 2n (n on the last layer): 12 MFMAs per 16-deep stage against 16 KiB of operand
+// fill, and its inputs and outputs (d_a_next, d_out, t, s read once; dg written once) are 378 MB per layer — HBM-bound by a
+// factor seven, so the kernel is shaped for streaming: small workgroups (one batch element × 128 samples, 50 KB of LDS,
+// three per CU), the t,s tiles of the first row block prefetched before the GEMM, the next block's while one is gated.
+// Image: S3 = 2·CH (CH on the last layer) stages × 4 row blocks × (1 KiB hi + 1 KiB lo), then 16 B of zeros; stage (src, c):
+// lane l holds W_rs[src·n + 16c + 8(l>>5) + j][blk·32 + (l&31)] — W_rs transposed, rows = acts channels.
+// ------------------------------------------------------------------------------------------------
+#define WN_BW_NB 4                                   // column blocks of a B row group (no tap shift: no spill block)
+#define WN_BW_GS (WN_BW_NB * 1024 + 128)
+#define WN_BW_A (4 * 2048)
+#define WN_BW_SLOT (WN_BW_A + 2 * WN_BW_GS)
+#define WN_BW_LDS (3 * WN_BW_SLOT)
+
+struct WnPackBwdParams {
+  const float* rs_w;   // [2n][n] (last: [n][n])
+  int n, last, CH;
+  uint4* img;
+};
+
+__global__ __launch_bounds__(64) void wn_pack_bwd_kernel(WnPackBwdParams p) {
+  const int lane = threadIdx.x, blk = blockIdx.x & 3, st = blockIdx.x >> 2;
+  const int n = p.n, hh = lane >> 5, m = blk * 32 + (lane & 31);
+  const int src = p.last ? 0 : st / p.CH, c = st - src * p.CH;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = 16 * c + 8 * hh + j;
+    v[j] = (m < n && ch < n) ? p.rs_w[(long long)(src * n + ch) * n + m] : 0.f;
+  }
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wn_split_pair(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+  uint4* dst = p.img + ((long long)st * 4 + blk) * 128 + lane;
+  dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  dst[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  if (blockIdx.x == 0 && lane == 0) p.img[(long long)gridDim.x * 128] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+extern "C" int64_t fst_wn_bwd_image_bytes(int n, int last) {
+  if (n <= 0) return -1;
+  return (int64_t)(last ? 1 : 2) * wn_ch(n) * WN_BW_A + 16;
+}
+
+extern "C" int fst_wn_pack_bwd(const float* rs_w, int n, int last, void* image, int64_t image_bytes, void* stream) {
+  FST_REQUIRE(rs_w && image && n > 0 && n <= 128, "fst_wn_pack_bwd: bad arguments (n=%d, needs n <= 128)", n);
+  FST_REQUIRE(image_bytes == fst_wn_bwd_image_bytes(n, last), "fst_wn_pack_bwd: image is %lld bytes, expected %lld",
+              (long long)image_bytes, (long long)fst_wn_bwd_image_bytes(n, last));
+  FST_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, "fst_wn_pack_bwd: image must be 16-byte aligned");
+  WnPackBwdParams p = {rs_w, n, last ? 1 : 0, wn_ch(n), static_cast<uint4*>(image)};
+  const int stages = (last ? 1 : 2) * p.CH;
+  hipLaunchKernelGGL(wn_pack_bwd_kernel, dim3((unsigned)(stages * 4)), dim3(64), 0, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+struct WnBwdParams {
+  const float* d_a;    // [B][n][L], null on the last layer
+  const float* d_out;  // [B][n][L]
+  const float* ts;     // [B][2n][L]
+  const char* img;
+  float* dg;           // [B][2n][L]
+  int B, L, n, last, CH, tiles_per_seq, n_wg;
+};
+
+// the four 16-byte pieces (rows rrow + 8j, samples c4..c4+3) a lane contributes to a 32×32 tile
+__device__ __forceinline__ void wn_fetch_tile(float4 (&q)[4], const float* src_rows, int rows_valid, int L, int t, int lane) {
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  const bool t_ok = t + c4 < L;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = rrow + 8 * j;
+    q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t_ok && row < rows_valid) q[j] = *reinterpret_cast<const float4*>(src_rows + (long long)row * L + t + c4);
+  }
+}
+// ... through the wave-private tile into the accumulator layout (lane = sample, registers = rows)
+__device__ __forceinline__ void wn_tile_to_acc(float (&v)[16], const float4 (&q)[4], float* tile, int lane) {
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(tile + (rrow + 8 * j) * 36 + c4) = q[j];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31];
+}
+
+__global__ __launch_bounds__(256, 3) void wn_layer_bwd_kernel(WnBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wg = blockIdx.x;
+  if ((p.n_wg & 7) == 0) wg = (wg & 7) * (p.n_wg >> 3) + (wg >> 3);
+  const int b = wg / p.tiles_per_seq;
+  const int t0 = (wg - b * p.tiles_per_seq) * WN_TN;
+  const int wave_n0 = wave_s * 32;
+  const int L = p.L, n = p.n, CH = p.CH;
+  const int S3 = (p.last ? 1 : 2) * CH;
+  const char* const zero16 = p.img + (long long)S3 * WN_BW_A;
+  const float* const ts_b = p.ts + (long long)b * (2 * n) * L;
+  const int tcol = t0 + wave_n0;
+
+  // pieces per stage: 8 of A, 2 x 4 of B = 16 -> exactly four per wave
+  auto issue = [&](int k, int slot) {
+    char* const sl = ldsb + slot * WN_BW_SLOT;
+    const char* asrc = p.img + (long long)k * WN_BW_A;
+    const bool from_da = !p.last && k < CH;
+    const int c = from_da ? k : k - (p.last ? 0 : CH);
+    const float* xb = (from_da ? p.d_a : p.d_out) + ((long long)b * n + 16 * c) * L;
+    const int c_count = min(16, n - 16 * c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = wave_s + 4 * i;
+      if (idx < 8) {
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+      } else {
+        const int bi = idx - 8;
+        const int gq = bi >> 2, m = bi & 3;
+        const int row = 8 * gq + (lane >> 3);
+        const int t = t0 + 32 * m + 4 * (lane & 7);
+        const bool ok = row < c_count && t < L;
+        const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_BW_A + gq * WN_BW_GS + m * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+  // The gate halves of the first row block, issued BEFORE any LDS-DMA: they are then the oldest vector-memory operations
+  // of the wave, so every counted wait below (which retires everything older than what it leaves in flight) covers them
+  // and the counts stay "pieces of the next stage".  First use is after the GEMM.
+  float4 qt[4], qs[4];
+  wn_fetch_tile(qt, ts_b, n, L, tcol, lane);
+  wn_fetch_tile(qs, ts_b + (long long)n * L, n, L, tcol, lane);
+  asm volatile("" ::: "memory");
+  issue(0, 0);
+  if (S3 > 1) issue(1, 1);
+  int slot = 0;
+  for (int k = 0; k < S3; ++k) {
+    if (k + 1 < S3) wn_wait_vmcnt<4>(); else wn_wait_vmcnt<0>();     // stage k landed; stage k+1's 4 pieces may fly on
+    __builtin_amdgcn_s_barrier();
+    if (k + 2 < S3) issue(k + 2, slot >= 1 ? slot - 1 : 2);
+    const char* base = ldsb + slot * WN_BW_SLOT;
+    const int colx = wave_n0 + l31;
+    const char* bp = base + WN_BW_A + half * WN_BW_GS + (colx >> 5) * 1024 + (colx & 31) * 4;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
+    wn_u32x4 bh4, bl4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned hh, ll;
+      wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
+      bh4[j] = hh; bl4[j] = ll;
+    }
+    const wn_bf16x8 bh = __builtin_bit_cast(wn_bf16x8, bh4), bl = __builtin_bit_cast(wn_bf16x8, bl4);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
+      const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  __syncthreads();                                     // every wave is past its last fragment read: the ring becomes tiles
+  float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
+  float* const dg_b = p.dg + (long long)b * (2 * n) * L;
+#pragma unroll
+  for (int blk = 0; blk < 4; ++blk) {
+    const int rows_valid = n - blk * 32;
+    float tv[16], sv[16], gt[16], gs[16];
+    wn_tile_to_acc(tv, qt, tile, lane);
+    wn_tile_to_acc(sv, qs, tile, lane);
+    if (blk < 3) {                                     // next row block's gate halves, in flight while this one is gated
+      wn_fetch_tile(qt, ts_b + (long long)((blk + 1) * 32) * L, n - (blk + 1) * 32, L, tcol, lane);
+      wn_fetch_tile(qs, ts_b + (long long)(n + (blk + 1) * 32) * L, n - (blk + 1) * 32, L, tcol, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = acc[blk][r], t = tv[r], s = sv[r];
+      gt[r] = d * s * (1.f - t * t);
+      gs[r] = d * t * s * (1.f - s);
+    }
+    wn_store_tile<0>(gt, tile, dg_b + (long long)(blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+    wn_store_tile<0>(gs, tile, dg_b + (long long)(n + blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+  }
+}
+
+extern "C" int fst_wn_layer_bwd(const float* d_a, const float* d_out, const float* ts, const void* image, int64_t image_bytes,
+                                float* dg, int last, int B, int L, int n, int64_t numel_a, void* stream) {
+  FST_REQUIRE(d_out && ts && image && dg && (last || d_a), "fst_wn_layer_bwd: null operand");
+  FST_REQUIRE(B > 0 && L > 0 && n > 0 && n <= 128, "fst_wn_layer_bwd: B=%d L=%d n=%d (needs n <= 128)", B, L, n);
+  FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_layer_bwd: B*n*L = %d*%d*%d does not match the element count %lld "
+              "of the [B, n, L] tensors", B, n, L, (long long)numel_a);
+  FST_REQUIRE(image_bytes == fst_wn_bwd_image_bytes(n, last), "fst_wn_layer_bwd: image is %lld bytes, expected %lld",
+              (long long)image_bytes, (long long)fst_wn_bwd_image_bytes(n, last));
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  FST_REQUIRE(L % 4 == 0 && al16(d_a) && al16(d_out) && al16(ts) && al16(image) && al16(dg),
+              "fst_wn_layer_bwd: needs L %% 4 == 0 and 16-byte aligned tensors (L=%d)", L);
+  WnBwdParams p;
+  p.d_a = last ? nullptr : d_a; p.d_out = d_out; p.ts = ts; p.img = static_cast<const char*>(image); p.dg = dg;
+  p.B = B; p.L = L; p.n = n; p.last = last ? 1 : 0; p.CH = wn_ch(n);
+  p.tiles_per_seq = (L + WN_TN - 1) / WN_TN;
+  p.n_wg = B * p.tiles_per_seq;
+  if (int rc = fst_allow_full_lds((const void*)wn_layer_bwd_kernel, "fst_wn_layer_bwd")) return rc;
+  hipLaunchKernelGGL(wn_layer_bwd_kernel, dim3((unsigned)p.n_wg), dim3(256), WN_BW_LDS, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}

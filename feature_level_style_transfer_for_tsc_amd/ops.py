@@ -702,6 +702,38 @@ def wn_layer_fwd(a: Tensor, u0: Tensor, img: Tensor, ts: Tensor, acts: Optional[
         KERNEL_TIMER.end("wn_layer_fwd_kernel", t0, flops, 4.0 * B * L * rows)
 
 
+def wn_pack_bwd(rs_w: Tensor, n: int, last: bool) -> Tensor:
+    lib = _lib.load()
+    key = None
+    if _PACK_CACHE is not None:
+        key = ("wn_bwd", n, last, rs_w.data_ptr(), rs_w._version)
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            return hit[0]
+    nbytes = lib.fst_wn_bwd_image_bytes(n, int(last))
+    img = torch.empty(nbytes // 4, device=rs_w.device, dtype=torch.float32)
+    src = rs_w.contiguous()
+    check(lib.fst_wn_pack_bwd(ptr(src), n, int(last), ptr(img), nbytes, stream_ptr()), "fst_wn_pack_bwd")
+    if key is not None:
+        _PACK_CACHE[key] = (img, rs_w, src)
+    return img
+
+
+def wn_layer_bwd(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, img: Tensor, dg: Tensor, last: bool, n: int) -> None:
+    lib = _lib.load()
+    B, _, L = d_out.shape
+    numel = _same_numel(d_out, d_a)
+    for t in (ts, dg):
+        if t.numel() != 2 * numel or not t.is_contiguous():
+            raise ValueError("wn_layer_bwd: ts / dg must be contiguous [B, 2n, L]")
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_wn_layer_bwd(ptr(d_a), ptr(d_out), ptr(ts), ptr(img), img.numel() * 4, ptr(dg), int(last), B, L, n, numel,
+                               stream_ptr()), "fst_wn_layer_bwd")
+    if t0 is not None:
+        k = n if last else 2 * n
+        KERNEL_TIMER.end("wn_layer_bwd_kernel", t0, 2.0 * B * L * n * k, 4.0 * B * L * (k + 4 * n))
+
+
 class WNFn(torch.autograd.Function):
     """The whole gated dilated-conv stack (:101-123) as one autograd node.
 
@@ -759,6 +791,7 @@ class WNFn(torch.autograd.Function):
                 S.rs[i].forward(acts, None, rs_w[i], None, rs_b[i], y=None, y2=out, msplit=0, flags=EPI_ACC2)
         o = S.end.forward(out, None, end_w, None, end_b)
         ctx.specs = S
+        ctx.fused = fused
         ctx.save_for_backward(u0, out, *a_list, *ts_list, *acts_list, start_w, cond_w, end_w, *in_w, *rs_w)
         return o
 
@@ -791,8 +824,10 @@ class WNFn(torch.autograd.Function):
         for i in reversed(range(nl)):
             last = i == nl - 1
             # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
-            dacts = torch.empty(B, n, L, device=dev, dtype=torch.float32)
-            if last:
+            dacts = None if ctx.fused else torch.empty(B, n, L, device=dev, dtype=torch.float32)
+            if ctx.fused:
+                pass
+            elif last:
                 bf3 = bf3_ok(S.rs_T_last, L)
                 a_pk = pack_weights(S.rs_T_last, n, rs_w[i], (0, 1, n, 0), bf3=bf3)
                 conv_gemm(S.rs_T_last, a_pk, d_out, None, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0),
@@ -811,8 +846,11 @@ class WNFn(torch.autograd.Function):
                     d_rs_b[i] = torch.cat([row_sum(d_a), d_out_sum])
             # ---- through the gate
             dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
-            check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]), stream_ptr()),
-                  "fst_gate_bwd")
+            if ctx.fused:
+                wn_layer_bwd(None if last else d_a, d_out, ts_list[i], wn_pack_bwd(rs_w[i], n, last), dg, last, n)
+            else:
+                check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]),
+                                       stream_ptr()), "fst_gate_bwd")
             if need_w:
                 dw0, dw1 = S.ins[i].grad_w(a_list[i], u0, dg)
                 d_in_w[i] = dw0

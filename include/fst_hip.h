@@ -187,6 +187,15 @@ int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, int64_t u0_b
                      float* ts, float* acts, float* a_next, float* out, int first, int last,
                      int B, int L, int n, int h, int dil, int64_t numel_a, void* stream);
 
+/* Backward of the same layer through res_skip and the gate, ONE launch:
+ *   dacts = W_rsᵀ·[d_a_next ; d_out]   (last layer: W_rsᵀ·d_out),   dg[:n] = dacts·s·(1−t²),  dg[n:] = dacts·t·s·(1−s)
+ * (the transposed 1x1 conv autograd derives for Simplified_NF_WaveGlow.py:116 and the gate backward of :44-54).
+ * ts = the (t | s) tensor fst_wn_layer_fwd saved; dg [B][2n][L] feeds the in_layer data / weight gradients. */
+int64_t fst_wn_bwd_image_bytes(int n, int last);
+int fst_wn_pack_bwd(const float* rs_w, int n, int last, void* image, int64_t image_bytes, void* stream);
+int fst_wn_layer_bwd(const float* d_a_next /* NULL iff last */, const float* d_out, const float* ts, const void* image,
+                     int64_t image_bytes, float* dg, int last, int B, int L, int n, int64_t numel_a, void* stream);
+
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */
 int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,

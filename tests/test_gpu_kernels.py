@@ -410,3 +410,22 @@ def test_fused_wn_layer_forward(n, h, B, L, dil, first, last):
     an2 = None if last else torch.empty_like(an_d)
     ops.wn_layer_fwd(ad, u0d, img, ts2, None, an2, out2, first, last, n, h, dil)
     assert torch.equal(ts2, ts_d) and torch.equal(out2, out_d)
+
+
+@pytest.mark.parametrize("n,B,L,last", [(120, 2, 512, False), (120, 3, 512, True), (120, 2, 200, False), (8, 3, 40, False),
+                                        (8, 2, 40, True), (128, 1, 256, False), (33, 2, 132, False)])
+def test_fused_wn_layer_backward(n, B, L, last):
+    """fst_wn_layer_bwd (transposed res_skip GEMM over [d_a ; d_out] -> gate backward in registers) against fp64 torch."""
+    g = torch.Generator().manual_seed(n * 100 + L + int(last))
+    rnd = lambda *s, k=1.0: torch.randn(*s, generator=g, dtype=torch.float64) * k
+    R = n if last else 2 * n
+    rs_w = rnd(R, n, k=n ** -0.5)
+    d_a, d_out = (None if last else rnd(B, n, L)), rnd(B, n, L)
+    t, s = torch.tanh(rnd(B, n, L)), torch.sigmoid(rnd(B, n, L))
+    d_r = d_out if last else torch.cat([d_a, d_out], 1)
+    dacts = torch.einsum("rm,brt->bmt", rs_w, d_r)
+    want = torch.cat([dacts * s * (1 - t * t), dacts * t * s * (1 - s)], 1)
+    f = lambda x: None if x is None else x.float().to(DEV).contiguous()
+    dg = torch.full((B, 2 * n, L), 7.0, device=DEV)
+    ops.wn_layer_bwd(f(d_a), f(d_out), f(torch.cat([t, s], 1)), ops.wn_pack_bwd(f(rs_w), n, last), dg, last, n)
+    assert_close(dg, want, 1e-5 * float(dacts.abs().max()) / max(1e-6, float(want.abs().max())) + 1e-6, "dg")
