@@ -159,6 +159,31 @@ extern "C" int fst_wn_pack(const float* in_w, const float* cond_w, const float* 
   return 0;
 }
 
+#ifdef FST_STAMPS
+// Diagnostic build only (tools/build_stamps.sh): per-phase s_memtime sums of the fused forward kernel, lane 0 of every wave.
+__device__ unsigned long long wn_stamps[12];
+__device__ __forceinline__ unsigned long long wn_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+extern "C" int fst_debug_wn_stamps(unsigned long long* out_host, int reset) {
+  if (out_host) hipMemcpyFromSymbol(out_host, HIP_SYMBOL(wn_stamps), sizeof(unsigned long long) * 12);
+  if (reset) { unsigned long long z[12] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(wn_stamps), z, sizeof(z)); }
+  return 0;
+}
+#define WN_T(var) const unsigned long long var = wn_now()
+#define WN_ACC(slot, a, b) wn_sum[slot] += (b) - (a)
+#define WN_SUMS unsigned long long wn_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define WN_FLUSH \
+  if (lane == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&wn_stamps[i_], wn_sum[i_])
+#else
+#define WN_T(var)
+#define WN_ACC(slot, a, b)
+#define WN_SUMS
+#define WN_FLUSH
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // forward layer
 // ------------------------------------------------------------------------------------------------
@@ -298,14 +323,25 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
   const int S = S1 + 8;
+  WN_SUMS;
+  WN_T(ts0);
   issue(0, 0);
   issue(1, 1);
   int slot = 0;
+  WN_T(ts1);
+  WN_ACC(0, ts0, ts1);                                 // prologue
   // ---------------------------------------------------------------- GEMM 1: g = [W_in | W_cond | b] · [a taps ; u0 ; 1]
   for (int k = 0; k < S1; ++k) {
+    WN_T(ta);
     wait_for(k + 1, S);
+    WN_T(tb);
+    WN_ACC(1, ta, tb);                                 // vmcnt wait
     __builtin_amdgcn_s_barrier();                      // stage k is in LDS for everyone; the slot refilled next is drained
+    WN_T(tc);
+    WN_ACC(2, tb, tc);                                 // barrier
     issue(k + 2, slot >= 1 ? slot - 1 : 2);            // (k + 2 < S always holds here: 8 k-steps of GEMM 2 follow)
+    WN_T(td);
+    WN_ACC(3, tc, td);                                 // LDS-DMA issue
     int shift = 0;
     if (k < 3 * CH) shift = (k / CH - 1) * p.dil;
     const int sub = (t0 + shift) & 3;
@@ -323,6 +359,11 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
       bh4[j] = hh; bl4[j] = ll;
     }
     const wn_bf16x8 bh = __builtin_bit_cast(wn_bf16x8, bh4), bl = __builtin_bit_cast(wn_bf16x8, bl4);
+#ifdef FST_STAMPS
+    asm volatile("" ::"v"(bh), "v"(bl));
+#endif
+    WN_T(te);
+    WN_ACC(4, td, te);                                 // B fragment: LDS reads + split
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
       const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
@@ -331,8 +372,11 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
     }
+    WN_T(tf);
+    WN_ACC(5, te, tf);                                 // A fragments + MFMA issue
     slot = slot == 2 ? 0 : slot + 1;
   }
+  WN_T(tg0);
 
   // ---------------------------------------------------------------- gate (between stage S1-1 and the first k-step of GEMM 2)
   // Drain: the two k-steps in flight (S1, S1+1: A only, L2 hits issued one and two stages ago) land, so from here on
@@ -380,6 +424,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     }
   }
   asm volatile("" ::: "memory");                       // the stores stay in front of the LDS-DMA issued below
+  WN_T(tg1);
+  WN_ACC(6, tg0, tg1);                                 // drain + gate + t,s stores (issue)
 
   // ---------------------------------------------------------------- GEMM 2: r = [W_rs | b] · [acts ; 1]
 #pragma unroll
@@ -405,6 +451,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     slot = slot == 2 ? 0 : slot + 1;
   }
 
+  WN_T(tg2);
+  WN_ACC(7, tg1, tg2);                                 // GEMM 2
   // ---------------------------------------------------------------- a_next = a + r[:n];  out (+)= r[n:]
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
@@ -422,6 +470,10 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     if (p.first) wn_store_tile<0>(v, tile, orow, nullptr, rows_valid, L, tcol, lane);
     else wn_store_tile<2>(v, tile, orow, nullptr, rows_valid, L, tcol, lane);
   }
+  WN_T(tg3);
+  WN_ACC(8, tg2, tg3);                                 // final epilogue (issue; includes waiting for the operand loads)
+  WN_ACC(9, ts0, tg3);                                 // whole wave
+  WN_FLUSH;
 }
 
 extern "C" int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, int64_t u0_bs, const void* image,

