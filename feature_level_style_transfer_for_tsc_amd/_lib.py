@@ -40,7 +40,7 @@ _SIGNATURES = {
     "fst_conv_gemm": (c_int, [_P, c_int64, _P, c_int64, _P, _I32P, _I32P, c_int, _P, _P, c_int64, _P, c_int64,
                               _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fst_conv_wgrad": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int, _P, _I32P, _I32P, c_int,
-                               c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                               c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_row_sum": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_void_p]),
     "fst_bn_stats": (c_int, [_P, c_int, c_int, c_int, _P, c_int64, c_void_p]),
     "fst_bn_finalize": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P, c_void_p]),
@@ -49,8 +49,8 @@ _SIGNATURES = {
     "fst_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_gate_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
-    "fst_coupling_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
-    "fst_coupling_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_coupling_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, _P, c_void_p]),
+    "fst_coupling_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_coupling_inv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_coupling_inv_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_image_bytes": (c_int64, [c_int, c_int]),

@@ -1184,6 +1184,7 @@ struct WgradParams {
   float* da;
   const int32_t* plan;
   int B, L, M, ksplit, tiles_per_seq, ldw, region_floats, n_regions;
+  long long x0_mul_off;   // != 0: the x operand is x0[i]·x0[i + x0_mul_off] (acts = t·s read from the saved gate halves)
 };
 
 #define WG_ITEMS 4   // row-blocks (32 packed K-rows each) per workgroup
@@ -1332,8 +1333,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
         } else {
           const int t = tt0 + reg_shift[r] + vcol;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (t >= 0 && t < L && vrow < reg_cnt[r])
-            v = *reinterpret_cast<const float4*>(reg_src[r] + ((long long)b * reg_bs[r] + (long long)vrow * L + t));
+          if (t >= 0 && t < L && vrow < reg_cnt[r]) {
+            const float* vp = reg_src[r] + ((long long)b * reg_bs[r] + (long long)vrow * L + t);
+            v = *reinterpret_cast<const float4*>(vp);
+            if (p.x0_mul_off) {
+              const float4 w = *reinterpret_cast<const float4*>(vp + p.x0_mul_off);
+              v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+            }
+          }
           x_st[r][0] = v.x; x_st[r][1] = v.y; x_st[r][2] = v.z; x_st[r][3] = v.w;
         }
       }
@@ -1373,7 +1380,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
         for (int i = 0; i < 4; ++i) {
           const int cc_even = wave_s * 2 + 8 * i;
           const float* rp = reg_src[r] + ((long long)b * reg_bs[r] + (long long)cc_even * L + tbase);
-          x_st[r][i] = (ok && cc_even + half < reg_cnt[r]) ? rp[vlane] : 0.f;
+          float xv = 0.f;
+          if (ok && cc_even + half < reg_cnt[r]) {
+            xv = rp[vlane];
+            if (p.x0_mul_off) xv *= rp[vlane + p.x0_mul_off];
+          }
+          x_st[r][i] = xv;
         }
       }
     }
@@ -1561,7 +1573,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
 extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs, const float* dy,
                               int64_t dy_bs, const float* dy2, int64_t dy2_bs, int msplit, float* da_packed,
                               const int32_t* plan_dev, const int32_t* plan_host, int plan_len, int B, int L, int M,
-                              int ksplit, int flags, void* stream) {
+                              int ksplit, int flags, int64_t x0_mul_off, void* stream) {
   if (int rc = fst_check_plan(plan_host, plan_len, M, "fst_conv_wgrad")) return rc;
   const PlanView pv = plan_view(plan_host);
   FST_REQUIRE(x0 && dy && da_packed && plan_dev, "fst_conv_wgrad: null operand");
@@ -1595,6 +1607,7 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   p.x[0] = x0; p.x[1] = x1; p.x_bs[0] = x0_bs; p.x_bs[1] = x1_bs;
   p.dy = dy; p.dy_bs = dy_bs; p.dy2 = dy2; p.dy2_bs = dy2_bs; p.msplit = msplit;
   p.da = da_packed; p.plan = plan_dev; p.B = B; p.L = L; p.M = M;
+  p.x0_mul_off = x0_mul_off;
   p.tiles_per_seq = (L + TW - 1) / TW;
   const int n_tiles = B * p.tiles_per_seq;
   p.ksplit = ksplit < n_tiles ? ksplit : n_tiles;
@@ -1622,6 +1635,9 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
     }
     p.n_regions = p.n_regions > distinct ? p.n_regions : distinct;
   }
+  FST_REQUIRE(x0_mul_off == 0 || (!wide && !needs_x1 && x0_mul_off % 4 == 0),
+              "fst_conv_wgrad: a product operand (x0_mul_off=%lld) needs a single-input, single-tap plan and a multiple-of-4 offset",
+              (long long)x0_mul_off);
   if (wide) {
     FST_REQUIRE(p.n_regions == 1 && pv.chunk_cap <= 64 && max_w <= 128,
                 "fst_conv_wgrad: windowed plan needs one chunk per workgroup, <= 64 channels, <= 128 columns "

@@ -283,63 +283,86 @@ extern "C" int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int 
 
 // ---------------------------------------------------------------- affine coupling
 // mode 0: forward   xn1 = exp(s)*u1 + b          mode 1: inverse   xn1 = (x1 - b) / exp(s)
-__global__ __launch_bounds__(256) void coupling_fwd_kernel(const float* u, const float* o, float* xn, int h, int L, int mode) {
+// sums (optional, forward mode): sums[0] += Σ log_s, sums[1] += Σ xn² — the two full-tensor reductions of WaveGlowLoss
+// (Simplified_NF_WaveGlow.py:230-241) taken while the tensors pass through anyway.
+__global__ __launch_bounds__(256) void coupling_fwd_kernel(const float* u, const float* o, float* xn, int h, int L, int mode,
+                                                           float* sums) {
   const int b = blockIdx.y;
   const long long half = (long long)h * L;
   const float* ub = u + (long long)b * 2 * half;
   const float* ob = o + (long long)b * 2 * half;
   float* xb = xn + (long long)b * 2 * half;
+  float acc_ls = 0.f, acc_sq = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < half; i += (long long)gridDim.x * 256) {
-    xb[i] = ub[i];
+    const float u0 = ub[i];
+    xb[i] = u0;
     const float bb = ob[i], s = ob[half + i], u1 = ub[half + i];
-    xb[half + i] = mode == 0 ? expf(s) * u1 + bb : (u1 - bb) / expf(s);
+    const float x1 = mode == 0 ? expf(s) * u1 + bb : (u1 - bb) / expf(s);
+    xb[half + i] = x1;
+    acc_ls += s;
+    acc_sq += u0 * u0 + x1 * x1;
+  }
+  if (sums) {                                            // kernel argument: uniform
+    block_sum2(acc_ls, acc_sq);
+    if (threadIdx.x == 0) {
+      atomicAdd(sums, acc_ls);
+      atomicAdd(sums + 1, acc_sq);
+    }
   }
 }
 
 static int launch_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int mode, int64_t numel,
-                               void* stream) {
+                               float* sums, void* stream) {
   FST_REQUIRE(u && o && xn && B > 0 && h > 0 && L > 0, "fst_coupling: bad arguments");
   FST_REQUIRE_EXTENT("fst_coupling", B, 2 * h, L, numel);
   long long blocks = ((long long)h * L + 255) / 256;
   if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(coupling_fwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, xn, h, L, mode);
+  hipLaunchKernelGGL(coupling_fwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, xn, h, L, mode, sums);
   FST_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int64_t numel, void* stream) {
-  return launch_coupling_fwd(u, o, xn, B, h, L, 0, numel, stream);
+extern "C" int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int64_t numel, float* sums,
+                                void* stream) {
+  return launch_coupling_fwd(u, o, xn, B, h, L, 0, numel, sums, stream);
 }
 extern "C" int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, int64_t numel,
                                     void* stream) {
-  return launch_coupling_fwd(x, o, xn, B, h, L, 1, numel, stream);
+  return launch_coupling_fwd(x, o, xn, B, h, L, 1, numel, nullptr, stream);
 }
 
-// forward-coupling backward.  dxn: grad of xn (2h ch); dlogs: extra grad flowing into log_s (may be null)
-//   du0 = dxn0 ; du1 = dxn1*exp(s) ; db = dxn1 ; ds = dxn1*u1*exp(s) + dlogs
+// forward-coupling backward.  dxn: grad of xn (2h ch, may be null = 0); dlogs: extra grad flowing into log_s (may be null);
+// gsums (may be null): DEVICE scalars (d/dΣlog_s, d/dΣxn²) of the fused loss reductions:  dxn_eff = dxn + 2·gsums[1]·xn
+//   du0 = dxn0 ; du1 = dxn1*exp(s) ; db = dxn1 ; ds = dxn1*u1*exp(s) + dlogs + gsums[0]
 __global__ __launch_bounds__(256) void coupling_bwd_kernel(const float* u, const float* o, const float* dxn,
-                                                           const float* dlogs, float* du, float* d_o, int h, int L) {
+                                                           const float* dlogs, const float* gsums, float* du, float* d_o,
+                                                           int h, int L) {
   const int b = blockIdx.y;
   const long long half = (long long)h * L;
   const long long off = (long long)b * 2 * half;
+  const float g_ls = gsums ? gsums[0] : 0.f, g_sq2 = gsums ? 2.f * gsums[1] : 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < half; i += (long long)gridDim.x * 256) {
     const float es = expf(o[off + half + i]);
-    const float g1 = dxn[off + half + i];
-    du[off + i] = dxn[off + i];
+    const float u0 = u[off + i], u1 = u[off + half + i];
+    const float x1 = es * u1 + o[off + i];
+    const float g0 = (dxn ? dxn[off + i] : 0.f) + g_sq2 * u0;
+    const float g1 = (dxn ? dxn[off + half + i] : 0.f) + g_sq2 * x1;
+    du[off + i] = g0;
     du[off + half + i] = g1 * es;
     d_o[off + i] = g1;
-    float ds = g1 * u[off + half + i] * es;
+    float ds = g1 * u1 * es + g_ls;
     if (dlogs) ds += dlogs[(long long)b * half + i];
     d_o[off + half + i] = ds;
   }
 }
 
-extern "C" int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, float* du,
-                                float* d_o, int B, int h, int L, int64_t numel, void* stream) {
-  FST_REQUIRE(u && o && dxn && du && d_o && B > 0 && h > 0 && L > 0, "fst_coupling_bwd: bad arguments");
+extern "C" int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, const float* gsums,
+                                float* du, float* d_o, int B, int h, int L, int64_t numel, void* stream) {
+  FST_REQUIRE(u && o && (dxn || gsums) && du && d_o && B > 0 && h > 0 && L > 0, "fst_coupling_bwd: bad arguments");
   FST_REQUIRE_EXTENT("fst_coupling_bwd", B, 2 * h, L, numel);
   long long blocks = ((long long)h * L + 255) / 256;
   if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, dxn, dlogs, du, d_o, h, L);
+  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, dxn, dlogs, gsums, du,
+                     d_o, h, L);
   FST_LAUNCH_CHECK();
   return 0;
 }

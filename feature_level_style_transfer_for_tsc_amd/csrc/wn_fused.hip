@@ -159,6 +159,13 @@ extern "C" int fst_wn_pack(const float* in_w, const float* cond_w, const float* 
   return 0;
 }
 
+// Diagnostic builds only (tools/build_wn_exp.sh): WN_EXP is a bit mask that removes one cost at a time from the fused
+// forward kernel (wrong results, timing only): 1 no MFMAs, 2 B pieces from the zero block (no activation fetch), 4 A pieces
+// from the zero block (no weight fetch), 8 no t,s / acts stores, 16 no final epilogue, 32 no B fragment reads / split.
+#ifndef WN_EXP
+#define WN_EXP 0
+#endif
+
 #ifdef FST_STAMPS
 // Diagnostic build only (tools/build_stamps.sh): per-phase s_memtime sums of the fused forward kernel, lane 0 of every wave.
 __device__ unsigned long long wn_stamps[12];
@@ -234,6 +241,45 @@ __device__ __forceinline__ void wn_store_tile(const float (&v)[16], float* tile,
   }
 }
 
+// the four 16-byte pieces (rows rrow + 8j, samples c4..c4+3) a lane contributes to a 32×32 tile
+__device__ __forceinline__ void wn_fetch_tile(float4 (&q)[4], const float* src_rows, int rows_valid, int L, int t, int lane) {
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  const bool t_ok = t + c4 < L;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = rrow + 8 * j;
+    q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t_ok && row < rows_valid) q[j] = *reinterpret_cast<const float4*>(src_rows + (long long)row * L + t + c4);
+  }
+}
+// ... through the wave-private tile into the accumulator layout (lane = sample, registers = rows)
+__device__ __forceinline__ void wn_tile_to_acc(float (&v)[16], const float4 (&q)[4], float* tile, int lane) {
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4, half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(tile + (rrow + 8 * j) * 36 + c4) = q[j];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31];
+}
+
+// accumulator tile + an operand tile fetched earlier (wn_fetch_tile) → dst.  Keeping the operand loads of tile i+1 in
+// flight while tile i is stored matters: vmcnt retires in issue order, so a load issued AFTER a store cannot be waited
+// for without waiting for that store's completion too (one HBM write latency per tile, serialised).
+__device__ __forceinline__ void wn_store_tile_add(const float (&v)[16], const float4 (&e)[4], float* tile, float* dst_rows,
+                                                  int rows_valid, int L, int t, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = v[r];
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  const bool t_ok = t + c4 < L;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = rrow + 8 * j;
+    float4 w = *reinterpret_cast<const float4*>(tile + row * 36 + c4);
+    w.x += e[j].x; w.y += e[j].y; w.z += e[j].z; w.w += e[j].w;
+    if (t_ok && row < rows_valid) *reinterpret_cast<float4*>(dst_rows + (long long)row * L + t + c4) = w;
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NA = WN_A_BYTES / 1024;              // 16 one-KiB pieces of A per stage
@@ -268,7 +314,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
       for (int i = 0; i < 4; ++i) {
         const int idx = a0 + wave_s + 4 * i;
         if (idx < NA)
-          __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((WN_EXP & 4) ? zero16 : asrc + idx * 1024 + lane * 16),
+                                           WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
       }
       return;
     }
@@ -295,7 +342,8 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
       const int idx = wave_s + 4 * i;
       if (idx >= NI1) break;                         // wave-uniform
       if (idx < NA) {
-        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((WN_EXP & 4) ? zero16 : asrc + idx * 1024 + lane * 16),
+                                         WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
       } else {
         const int bi = idx - NA;
         const int gq = bi >= WN_NBLK ? 1 : 0, m = bi - gq * WN_NBLK;
@@ -303,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
         const int t = t4 + 32 * m + 4 * (lane & 7);
         bool ok = row < c_count && t >= 0 && t < L;
         if (m == WN_NBLK - 1) ok = ok && spill && (lane & 7) == 0;
+        if (WN_EXP & 2) ok = false;
         const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : (row == ones_row ? ones16 : zero16);
         __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_A_BYTES + gq * WN_GS + m * 1024), 16, 0, 0);
       }
@@ -350,12 +399,13 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     const char* bp = base + WN_A_BYTES + half * WN_GS + (colx >> 5) * 1024 + (colx & 31) * 4;
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
+    for (int j = 0; j < 8; ++j) v[j] = (WN_EXP & 32) ? (float)(k + j) : *reinterpret_cast<const float*>(bp + j * 128);
     wn_u32x4 bh4, bl4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       unsigned hh, ll;
-      wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
+      if (WN_EXP & 32) { hh = __float_as_uint(v[2 * j]); ll = __float_as_uint(v[2 * j + 1]); }
+      else wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
       bh4[j] = hh; bl4[j] = ll;
     }
     const wn_bf16x8 bh = __builtin_bit_cast(wn_bf16x8, bh4), bl = __builtin_bit_cast(wn_bf16x8, bl4);
@@ -368,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     for (int mb = 0; mb < 8; ++mb) {
       const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
       const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+      if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh), "v"(bl)); continue; }
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
@@ -401,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
       const int row = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       av[r] = row == n ? 1.0f : tv[r] * sv[r];         // acts[n] = 1 carries b_rs through GEMM 2 (rows > n: tanh(0)·σ(0) = 0)
     }
-    const int rows_valid = n - blk * 32;               // may be <= 0: nothing stored
+    const int rows_valid = (WN_EXP & 8) ? 0 : n - blk * 32;               // may be <= 0: nothing stored
     wn_store_tile<0>(tv, tile, ts_b + (long long)(blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
     wn_store_tile<0>(sv, tile, ts_b + (long long)(n + blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
     if (p.acts) {
@@ -444,6 +495,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
       if (p.last && mb < 4) continue;                  // wave-uniform
       const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
       const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+      if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh2[ks]), "v"(bl2[ks])); continue; }
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh2[ks], acc[mb], 0, 0, 0);
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2[ks], acc[mb], 0, 0, 0);
       acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh2[ks], acc[mb], 0, 0, 0);
@@ -454,21 +506,28 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   WN_T(tg2);
   WN_ACC(7, tg1, tg2);                                 // GEMM 2
   // ---------------------------------------------------------------- a_next = a + r[:n];  out (+)= r[n:]
+  // eight tiles: residual block i/2 (i even: a_next = r + a) and skip block i/2 (i odd: out = r (+ out)); the operand
+  // tile of i+1 is fetched before tile i is stored
+  auto e_src = [&](int i) -> const float* {
+    const int blk = i >> 1;
+    return (i & 1) ? p.out + ((long long)b * n + blk * 32) * L : ab + (long long)(blk * 32) * L;
+  };
+  auto e_rows = [&](int i) -> int {                    // rows to fetch: none for tiles that have no operand
+    if (i & 1) return p.first ? 0 : n - (i >> 1) * 32;
+    return p.last ? 0 : n - (i >> 1) * 32;
+  };
+  float4 eq[2][4];
+  wn_fetch_tile(eq[0], e_src(0), e_rows(0), L, tcol, lane);
 #pragma unroll
-  for (int blk = 0; blk < 4; ++blk) {
-    const int rows_valid = n - blk * 32;
+  for (int i = 0; i < ((WN_EXP & 16) ? 1 : 8); ++i) {
+    if (i + 1 < 8) wn_fetch_tile(eq[(i + 1) & 1], e_src(i + 1), e_rows(i + 1), L, tcol, lane);
+    const int blk = i >> 1;
+    if (!(i & 1) && p.last) continue;                  // no residual rows on the last layer
     float v[16];
-    if (!p.last) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = acc[blk][r];
-      wn_store_tile<1>(v, tile, p.a_next + ((long long)b * n + blk * 32) * L, ab + (long long)(blk * 32) * L, rows_valid, L,
-                       tcol, lane);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[blk + 4][r];
-    float* orow = p.out + ((long long)b * n + blk * 32) * L;
-    if (p.first) wn_store_tile<0>(v, tile, orow, nullptr, rows_valid, L, tcol, lane);
-    else wn_store_tile<2>(v, tile, orow, nullptr, rows_valid, L, tcol, lane);
+    for (int r = 0; r < 16; ++r) v[r] = acc[(i & 1) ? blk + 4 : blk][r];
+    float* dst = ((i & 1) ? p.out : p.a_next) + ((long long)b * n + blk * 32) * L;
+    wn_store_tile_add(v, eq[i & 1], tile, dst, n - blk * 32, L, tcol, lane);
   }
   WN_T(tg3);
   WN_ACC(8, tg2, tg3);                                 // final epilogue (issue; includes waiting for the operand loads)
@@ -569,26 +628,6 @@ struct WnBwdParams {
   float* dg;           // [B][2n][L]
   int B, L, n, last, CH, tiles_per_seq, n_wg;
 };
-
-// the four 16-byte pieces (rows rrow + 8j, samples c4..c4+3) a lane contributes to a 32×32 tile
-__device__ __forceinline__ void wn_fetch_tile(float4 (&q)[4], const float* src_rows, int rows_valid, int L, int t, int lane) {
-  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
-  const bool t_ok = t + c4 < L;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = rrow + 8 * j;
-    q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t_ok && row < rows_valid) q[j] = *reinterpret_cast<const float4*>(src_rows + (long long)row * L + t + c4);
-  }
-}
-// ... through the wave-private tile into the accumulator layout (lane = sample, registers = rows)
-__device__ __forceinline__ void wn_tile_to_acc(float (&v)[16], const float4 (&q)[4], float* tile, int lane) {
-  const int rrow = lane >> 3, c4 = (lane & 7) * 4, half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(tile + (rrow + 8 * j) * 36 + c4) = q[j];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31];
-}
 
 __global__ __launch_bounds__(256, 3) void wn_layer_bwd_kernel(WnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -242,7 +242,7 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
 
 
 def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor], msplit: int, B: int,
-               L: int, M: int, ksplit: int) -> Tensor:
+               L: int, M: int, ksplit: int, x0_mul_off: int = 0) -> Tensor:
     lib = _lib.load()
     da = torch.zeros(plan.packed_floats, device=x0.device, dtype=torch.float32)
     x0_bs, _ = _ncl(x0, "x0")
@@ -253,7 +253,7 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
     bf3 = MATH == "bf16x3"
     check(lib.fst_conv_wgrad(ptr(x0), x0_bs, ptr(x1), x1_bs, ptr(dy), dy_bs, ptr(dy2), dy2_bs, msplit, ptr(da),
                              ptr(plan.dev(x0.device)), plan.host_ptr(), plan.length, B, L, M, ksplit,
-                             GEMM_BF16X3 if bf3 else 0, stream_ptr()), "fst_conv_wgrad")
+                             GEMM_BF16X3 if bf3 else 0, x0_mul_off, stream_ptr()), "fst_conv_wgrad")
     if t0 is not None:
         wide = bool(((plan.entries()[:, :, 1] - plan.entries()[:, :, 0]) > 1).any())
         if wide:
@@ -494,12 +494,13 @@ class ConvSpec:
         return out
 
     def grad_w(self, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor] = None,
-               msplit: Optional[int] = None) -> Tuple[Tensor, Optional[Tensor]]:
+               msplit: Optional[int] = None, x0_mul_off: int = 0) -> Tuple[Tensor, Optional[Tensor]]:
+        """``x0_mul_off``: the x operand is x0[i]·x0[i + x0_mul_off] (x0 = a row slice of the saved gate halves)."""
         B, L = x0.size(0), x0.size(2)
         plan = self.wg_plan()
         n_wg = max(1, len(plan.items()) // 4)
         da = conv_wgrad(plan, x0, x1, dy, dy2, self.M if msplit is None else msplit, B, L, self.M,
-                        wgrad_ksplit(B, L, n_wg))
+                        wgrad_ksplit(B, L, n_wg), x0_mul_off)
         # a dense plan (every tap of every row) makes unpack write every element: no zero fill needed
         alloc = torch.empty if (self.dense_dw or self.row_live is None) else torch.zeros
         dw0 = alloc(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
@@ -765,11 +766,10 @@ class WNFn(torch.autograd.Function):
                 last = i == nl - 1
                 img = wn_pack_layer(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], in_b[i], cb[i], rs_w[i], rs_b[i], n, h, last)
                 ts = torch.empty(B, 2 * n, L, device=u0.device, dtype=torch.float32)
-                acts = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
                 a_next = None if last else torch.empty_like(a)
-                wn_layer_fwd(a, u0, img, ts, acts, a_next, out, i == 0, last, n, h, 2 ** i)
+                # acts = t·s is not written: the res_skip weight gradient re-forms it from the saved halves while staging
+                wn_layer_fwd(a, u0, img, ts, None, a_next, out, i == 0, last, n, h, 2 ** i)
                 ts_list.append(ts)
-                acts_list.append(acts)
                 if not last:
                     a = a_next
                     a_list.append(a)
@@ -792,6 +792,8 @@ class WNFn(torch.autograd.Function):
         o = S.end.forward(out, None, end_w, None, end_b)
         ctx.specs = S
         ctx.fused = fused
+        if fused:
+            acts_list = ts_list                                           # placeholders (same count) for the saved-tensor layout
         ctx.save_for_backward(u0, out, *a_list, *ts_list, *acts_list, start_w, cond_w, end_w, *in_w, *rs_w)
         return o
 
@@ -838,11 +840,14 @@ class WNFn(torch.autograd.Function):
                 conv_gemm(S.rs_T, a_pk, d_a, d_out, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0),
                           bf3=bf3)
             if need_w:
+                # fused forward: acts = t·s is re-formed from the saved halves (rows [0,n) and [n,2n) of ts) while staging
+                x_rs = ts_list[i][:, :n] if ctx.fused else acts_list[i]
+                mul = n * L if ctx.fused else 0
                 if last:
-                    d_rs_w[i], _ = S.rs[i].grad_w(acts_list[i], None, d_out)
+                    d_rs_w[i], _ = S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul)
                     d_rs_b[i] = d_out_sum
                 else:
-                    d_rs_w[i], _ = S.rs[i].grad_w(acts_list[i], None, d_a, d_out, msplit=n)
+                    d_rs_w[i], _ = S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul)
                     d_rs_b[i] = torch.cat([row_sum(d_a), d_out_sum])
             # ---- through the gate
             dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
@@ -870,7 +875,8 @@ class WNFn(torch.autograd.Function):
 
 
 class CouplingFn(torch.autograd.Function):
-    """x_next = cat(u0, exp(log_s)·u1 + b) with (b, log_s) = split(o) (:173-178)."""
+    """x_next = cat(u0, exp(log_s)·u1 + b) with (b, log_s) = split(o) (:173-178).  Also returns [Σ log_s, Σ x_next²]
+    (a 2-element tensor) taken in the same pass: the full-tensor reductions of WaveGlowLoss (:230-241)."""
 
     @staticmethod
     def forward(ctx, u, o):
@@ -878,18 +884,23 @@ class CouplingFn(torch.autograd.Function):
         u, o = u.contiguous(), o.contiguous()
         B, C, L = u.shape
         xn = torch.empty_like(u)
-        check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, _same_numel(u, o, xn), stream_ptr()), "fst_coupling_fwd")
+        sums = torch.zeros(2, device=u.device, dtype=torch.float32)
+        check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, _same_numel(u, o, xn), ptr(sums), stream_ptr()),
+              "fst_coupling_fwd")
         ctx.save_for_backward(u, o)
-        return xn
+        return xn, sums
 
     @staticmethod
-    def backward(ctx, dxn):
+    def backward(ctx, dxn, dsums):
         lib = _lib.load()
         u, o = ctx.saved_tensors
         B, C, L = u.shape
         du, d_o = torch.empty_like(u), torch.empty_like(o)
-        dxn = dxn.contiguous()
-        check(lib.fst_coupling_bwd(ptr(u), ptr(o), ptr(dxn), None, ptr(du), ptr(d_o), B, C // 2, L,
+        dxn = None if dxn is None else dxn.contiguous()
+        gs = None if dsums is None else dsums.contiguous().float()
+        if dxn is None and gs is None:
+            return torch.zeros_like(u), torch.zeros_like(o)
+        check(lib.fst_coupling_bwd(ptr(u), ptr(o), ptr(dxn), None, ptr(gs), ptr(du), ptr(d_o), B, C // 2, L,
                                    _same_numel(u, o, dxn, du, d_o), stream_ptr()), "fst_coupling_bwd")
         return du, d_o
 

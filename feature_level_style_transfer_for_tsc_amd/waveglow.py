@@ -130,8 +130,13 @@ class WaveGlow(nn.Module):
             audio, log_det_W = self.convinv[k](audio)
             log_det_W_list.append(log_det_W)
             output = self.WN[k](audio[:, :n_half, :])
-            log_s_list.append(output[:, n_half:, :])
-            audio = ops.CouplingFn.apply(audio, output)
+            log_s = output[:, n_half:, :]
+            audio, sums = ops.CouplingFn.apply(audio, output)
+            # Σ log_s of this flow (and Σ z² after the last one) were reduced inside the coupling kernel; WaveGlowLoss picks
+            # them up from here instead of re-reading the tensors (the returned tensors themselves are the reference's)
+            log_s._fst_sum = sums[0]
+            audio._fst_sq_sum = sums[1]
+            log_s_list.append(log_s)
         return audio, log_s_list, log_det_W_list
 
     def infer(self, audio: torch.Tensor, sigma: float = 1.0) -> torch.Tensor:
@@ -153,10 +158,14 @@ class WaveGlowLoss(nn.Module):
 
     def forward(self, model_output):
         z, log_s_list, log_det_W_list = model_output
-        log_s_total = log_s_list[0].sum()
+        # sums already reduced by the coupling kernels (WaveGlow.forward) when present; any other tensors are summed here
+        total = lambda t, attr: getattr(t, attr) if hasattr(t, attr) else None
+        sums_ls = [total(t, "_fst_sum") for t in log_s_list]
+        log_s_total = sums_ls[0] if sums_ls[0] is not None else log_s_list[0].sum()
         log_det_W_total = log_det_W_list[0]
-        for log_s, log_det in zip(log_s_list[1:], log_det_W_list[1:]):
-            log_s_total = log_s_total + log_s.sum()
+        for log_s, s_ls, log_det in zip(log_s_list[1:], sums_ls[1:], log_det_W_list[1:]):
+            log_s_total = log_s_total + (s_ls if s_ls is not None else log_s.sum())
             log_det_W_total = log_det_W_total + log_det
-        loss = torch.sum(z * z) / (2 * self.sigma * self.sigma) - log_s_total - log_det_W_total
+        sq = total(z, "_fst_sq_sum")
+        loss = (sq if sq is not None else torch.sum(z * z)) / (2 * self.sigma * self.sigma) - log_s_total - log_det_W_total
         return loss / (z.size(0) * z.size(1) * z.size(2))

@@ -113,11 +113,14 @@ int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs
  * gradient autograd derives for every conv listed above (Q1: with a dense plan it also yields the
  * masked-tap gradients the reference's GradNorm consumes, train_and_test.py:685-690).
  * FST_GEMM_BF16X3: products on v_mfma_f32_32x32x16_bf16 with both operands split into two bf16 parts
- * (hi*hi + hi*lo + lo*hi, fp32 accumulate), same layout of da_packed. */
+ * (hi*hi + hi*lo + lo*hi, fp32 accumulate), same layout of da_packed.
+ * x0_mul_off != 0 (single-input 1x1 plans only): the x operand is the elementwise product x0[i]·x0[i + x0_mul_off] formed
+ * while staging — the res_skip weight gradient reads acts = t·s from the gate halves the fused forward saved
+ * (x0 = the t rows of ts, offset n·L to the s rows), so acts itself is never written to HBM. */
 int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs,
                    const float* dy, int64_t dy_bs, const float* dy2, int64_t dy2_bs, int msplit,
                    float* da_packed, const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
-                   int B, int L, int M, int ksplit, int flags /* 0 or FST_GEMM_BF16X3 */, void* stream);
+                   int B, int L, int M, int ksplit, int flags /* 0 or FST_GEMM_BF16X3 */, int64_t x0_mul_off, void* stream);
 
 /* out[m] (+)= Σ_{b,t} x[b,m,t]   (bias gradients; BN β gradient). */
 int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, void* stream);
@@ -155,10 +158,13 @@ int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const fl
 int fst_gate_fwd(float* g_ts, float* acts, int B, int n, int L, int64_t numel_acts, void* stream);
 /* dg[:n] = dacts·s·(1−t²), dg[n:] = dacts·t·s·(1−s) */
 int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, int L, int64_t numel_acts, void* stream);
-/* affine coupling (:173-178): xn[:, :h]=u[:, :h]; xn[:, h:] = exp(o[:, h:])·u[:, h:] + o[:, :h] */
-int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int64_t numel, void* stream);
-/* backward of the above given dxn and (added) d_logs; writes du (full 2h channels: du[:, :h]=dxn[:, :h]) and do */
-int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs,
+/* affine coupling (:173-178): xn[:, :h]=u[:, :h]; xn[:, h:] = exp(o[:, h:])·u[:, h:] + o[:, :h].
+ * sums (optional float[2], accumulated): sums[0] += Σ log_s (= Σ o[:, h:]), sums[1] += Σ xn² — the full-tensor reductions of
+ * WaveGlowLoss (Simplified_NF_WaveGlow.py:230-241) taken in the same pass. */
+int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int64_t numel, float* sums, void* stream);
+/* backward of the above given dxn (may be NULL = 0) and (added) d_logs; gsums (optional DEVICE float[2]) = the cotangents of
+ * the two sums: dxn_eff = dxn + 2·gsums[1]·xn, d log_s += gsums[0]; writes du (full 2h channels) and do */
+int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, const float* gsums,
                      float* du, float* d_o, int B, int h, int L, int64_t numel, void* stream);
 /* inverse coupling (:193-196): xn[:, h:] = (x[:, h:] − o[:, :h]) / exp(o[:, h:]) */
 int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, int64_t numel, void* stream);

@@ -1,10 +1,10 @@
 """Diagnostic: whole joint step vs the oracle — per-parameter gradient error (max |err| / module scale, relative L2).
-usage: python tools/grad_diag.py [L] [B] [seed]   (FST_MATH=f32|bf16x3 picks the arithmetic)"""
+usage: python tests/diag_grad_vs_oracle.py [L] [B] [seed]   (FST_MATH=f32|bf16x3 picks the arithmetic)"""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # lives under tests/: only tests may import the oracle
 import numpy as np
 import torch
 import feature_level_style_transfer_for_tsc_amd as fst

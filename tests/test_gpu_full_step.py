@@ -57,8 +57,10 @@ def _step_both(js, tr, batch, ts):
 # Split-bf16 mode: 2e-3, EXCEPT the feature extractors: the weight gradient of a conv in front of a train-mode BatchNorm
 # is a sum over (b, t) of dy·x with dy orthogonal to both 1 and x-hat — at L = 512 it cancels to ~1/600 of Σ|dy·x| (the
 # exact-f32 path itself measures 4e-5 = 600 fp32 epsilons there), so the 4e-6 per-product error of the three-MFMA split
-# shows as 2.6e-3 of the gradient scale (tools/grad_diag.py).  6e-3 leaves a factor two.
-GRAD_TOL = {"f32": {"default": 1e-3}, "bf16x3": {"default": 2e-3, "fe_t": 6e-3, "fe_s": 6e-3}}
+# shows as 2.6e-3 of the gradient scale at B=4 (tests/diag_grad_vs_oracle.py) and up to 1.1e-2 at B=3 (four-source test): the
+# ratio to the f32 path stays ~65 = 4e-6 / 6e-8, the amplification is the data's.  GradNorm's norms of these gradients
+# are held to 1e-3 above; FST_MATH=f32 gives the exact-f32 gradients where they matter more than speed.
+GRAD_TOL = {"f32": {"default": 1e-3}, "bf16x3": {"default": 2e-3, "fe_t": 2e-2, "fe_s": 2e-2}}
 
 
 @pytest.fixture(params=["bf16x3", "f32"])

@@ -228,11 +228,21 @@ def test_gate_and_coupling():
     o = (torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
     xn = torch.cat([u[:, :h], torch.exp(o[:, h:]) * u[:, h:] + o[:, :h]], 1)
     r = torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64)
-    ((xn * r).sum() + o[:, h:].sum() * 0.5).backward()
+    ((xn * r).sum() + o[:, h:].sum() * 0.5 + (xn * xn).sum() * 0.25).backward()
     ud, od = u.detach().float().to(DEV).requires_grad_(True), o.detach().float().to(DEV).requires_grad_(True)
-    xnd = ops.CouplingFn.apply(ud, od)
-    ((xnd * r.float().to(DEV)).sum() + od[:, h:].sum() * 0.5).backward()
+    xnd, sums = ops.CouplingFn.apply(ud, od)                             # sums = [Σ log_s, Σ xn²], reduced in the same pass
+    assert abs(float(sums[0]) - float(o[:, h:].sum())) <= 1e-5 * float(o[:, h:].abs().sum())
+    assert abs(float(sums[1]) - float((xn * xn).sum())) <= 1e-5 * float((xn * xn).sum())
+    ((xnd * r.float().to(DEV)).sum() + sums[0] * 0.5 + sums[1] * 0.25).backward()
     assert_close(xnd, xn, 1e-5, "coupling fwd"); assert_close(ud.grad, u.grad, 1e-5, "du"); assert_close(od.grad, o.grad, 1e-5, "do")
+    # only the sums are used (no gradient reaches xn directly)
+    ud2, od2 = ud.detach().clone().requires_grad_(True), od.detach().clone().requires_grad_(True)
+    _, sums2 = ops.CouplingFn.apply(ud2, od2)
+    (sums2[1] * 0.5 - sums2[0]).backward()
+    u3, o3 = u.detach().clone().requires_grad_(True), o.detach().clone().requires_grad_(True)
+    xn3 = torch.cat([u3[:, :h], torch.exp(o3[:, h:]) * u3[:, h:] + o3[:, :h]], 1)
+    ((xn3 * xn3).sum() * 0.5 - o3[:, h:].sum()).backward()
+    assert_close(ud2.grad, u3.grad, 1e-5, "du (sums only)"); assert_close(od2.grad, o3.grad, 1e-5, "do (sums only)")
 
     x = torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64, requires_grad=True)
     o2 = (torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
@@ -429,3 +439,22 @@ def test_fused_wn_layer_backward(n, B, L, last):
     dg = torch.full((B, 2 * n, L), 7.0, device=DEV)
     ops.wn_layer_bwd(f(d_a), f(d_out), f(torch.cat([t, s], 1)), ops.wn_pack_bwd(f(rs_w), n, last), dg, last, n)
     assert_close(dg, want, 1e-5 * float(dacts.abs().max()) / max(1e-6, float(want.abs().max())) + 1e-6, "dg")
+
+
+def test_weight_gradient_with_product_operand(arithmetic):
+    """res_skip weight gradient with x = t·s formed while staging (x0 = the t rows of the saved [B, 2n, L] gate halves,
+    x0_mul_off = n·L to the s rows) equals the gradient against a materialised acts tensor."""
+    g = torch.Generator().manual_seed(77)
+    for n, B, L, M in ((120, 2, 512, 240), (8, 3, 40, 8), (33, 2, 132, 66)):
+        ts = torch.randn(B, 2 * n, L, generator=g, dtype=torch.float64)
+        dy = torch.randn(B, M, L, generator=g, dtype=torch.float64)
+        acts = ts[:, :n] * ts[:, n:]
+        want = torch.einsum("bmt,bct->mc", dy, acts)
+        spec = ops.ConvSpec(M, n)
+        tsd = ts.float().to(DEV)
+        if M == 2 * n:
+            dyd = dy.float().to(DEV)
+            dw, _ = spec.grad_w(tsd[:, :n], None, dyd[:, :n].contiguous(), dyd[:, n:].contiguous(), msplit=n, x0_mul_off=n * L)
+        else:
+            dw, _ = spec.grad_w(tsd[:, :n], None, dy.float().to(DEV), x0_mul_off=n * L)
+        assert_close(dw[:, :, 0], want, 1e-4, f"dW with product operand n={n}")
