@@ -62,7 +62,8 @@ _SIGNATURES = {
     "fst_wn_layer_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_axpy": (c_int, [_P, _P, c_float, c_int64, c_void_p]),
     "fst_add_slices": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_void_p]),
-    "fst_cpc_nce_fwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_void_p]),
+    "fst_cpc_workspace_floats": (c_int64, [c_int, c_int, c_int]),
+    "fst_cpc_nce_fwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_void_p]),
     "fst_cpc_nce_bwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                                 c_void_p]),
 }

@@ -11,6 +11,11 @@
 // Rows (enc samples, B) and columns (pred samples = negatives, Bc) may differ: in "global batch" data
 // parallelism a rank scores its B local rows against the Bc = world·B gathered predictions, its own
 // positives sitting at columns col_off + b (SURVEY §8e mode B).  Single GPU: Bc = B, col_off = 0.
+//
+// More than 256 columns (8 ranks x 256 samples = 2048 negatives): the columns are cut into PANELS of 256 that fit LDS;
+// a workgroup handles one panel (blockIdx.z / .y), the forward leaves per-(row, panel) partial (max, Σexp, diagonal) in a
+// workspace that cpc_combine_kernel merges (online-softmax combine: lse = M + log Σ_p s_p·e^{m_p − M}), the backward —
+// lse known — is independent per panel: dpred rows of the panel written, denc accumulated over panels with fp32 atomics.
 #include "fst_common.h"
 
 #define CPC_ROWS 16
@@ -38,6 +43,8 @@ struct CpcParams {
   const int* t0_dev;   // optional device scalar: extra time offset of enc/denc (elements of stride s_i)
   int T, B, C;
   int Bc, col_off;     // columns (pred rows) and the column of row 0's positive
+  int n_panels;        // column panels of CPC_PANEL (1 when Bc <= CPC_PANEL)
+  float* ws;           // [T][B][n_panels][3] partial (max, Σexp, diag) — forward, n_panels > 1 only
 };
 
 // Forward: the Gram product on the matrix cores.  A workgroup owns 32 rows (encodings) of step i against all Bc
@@ -46,17 +53,19 @@ struct CpcParams {
 // ([rows][C|1], odd stride: lane <-> row reads hit distinct banks).  The log-softmax over a row runs on the
 // accumulators: C/D layout puts a tile's 32 columns on the 32 lanes of a half-wave and 16 rows in its registers, so a
 // row's max / Σexp / diagonal is a 5-step butterfly inside the half-wave, then a 4-entry combine through LDS.
-#define CPC_MAXTILES 2   // column tiles per wave: Bc <= 4 * 32 * CPC_MAXTILES = 256
+#define CPC_MAXTILES 2   // column tiles per wave: a panel is <= 4 * 32 * CPC_MAXTILES = 256 columns
+#define CPC_PANEL (128 * CPC_MAXTILES)
 
 __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (p.t0_dev) p.enc += (long long)p.t0_dev[0] * p.s_i;
   const int i = blockIdx.x;
-  const int B = p.B, Bc = p.Bc, C = p.C, PS = C | 1;
+  const int col0 = blockIdx.z * CPC_PANEL;     // this workgroup's column panel [col0, col0 + Bc)
+  const int B = p.B, Bc = min(CPC_PANEL, p.Bc - col0), C = p.C, PS = C | 1;
   float* predl = lds;                          // [Bc][PS]   staged once per workgroup
   float* encl = predl + (size_t)Bc * PS;       // [32][PS]   one row block at a time
   float* red = encl + 32 * PS;                 // [3][4 waves][32 rows]: max, Σexp, diagonal
-  const float* predg = p.pred + (long long)i * Bc * C;
+  const float* predg = p.pred + ((long long)i * p.Bc + col0) * C;
   for (int idx = threadIdx.x; idx < Bc * C; idx += 256) {
     const int j = idx / C, c = idx - j * C;
     predl[j * PS + c] = predg[idx];
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
       const int j = (wave + 4 * t) * 32 + l31;
       if (wave + 4 * t < ntiles && j < Bc) {
         m = fmaxf(m, acc[t][r]);
-        if (j == r0 + row + p.col_off) d = acc[t][r];
+        if (col0 + j == r0 + row + p.col_off) d = acc[t][r];
       }
     }
 #pragma unroll
@@ -134,16 +143,39 @@ __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
       const float d4 = red[256 + row] + red[288 + row] + red[320 + row] + red[352 + row];
       const float lse = mx[r] + logf(s4);
       if (l31 == 0 && b < B) {
-        p.lse[(long long)i * B + b] = lse;
-        local += d4 - lse;
+        if (p.n_panels == 1) {
+          p.lse[(long long)i * B + b] = lse;
+          local += d4 - lse;
+        } else {                                 // partial statistics of this panel; cpc_combine_kernel merges them
+          float* w = p.ws + (((long long)i * B + b) * p.n_panels + blockIdx.z) * 3;
+          w[0] = mx[r]; w[1] = s4; w[2] = d4;
+        }
       }
     }
   }
   }   // row blocks
-  if (wave == 0) {
+  if (wave == 0 && p.n_panels == 1) {
     local += __shfl_xor(local, 32, 64);                    // the two halves hold different rows
     if (lane == 0) atomicAdd(p.nce_sum, local);
   }
+}
+
+// merge the per-panel partials of one (step, row): lse = M + log Σ_p s_p·e^{m_p − M}, nce_sum += Σ_p d_p − lse
+__global__ __launch_bounds__(256) void cpc_combine_kernel(CpcParams p) {
+  const long long n = (long long)p.T * p.B;
+  float local = 0.f;
+  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long long)gridDim.x * 256) {
+    const float* w = p.ws + r * p.n_panels * 3;
+    float M = -INFINITY, d = 0.f;
+    for (int q = 0; q < p.n_panels; ++q) M = fmaxf(M, w[3 * q]);
+    float S = 0.f;
+    for (int q = 0; q < p.n_panels; ++q) { S += w[3 * q + 1] * expf(w[3 * q] - M); d += w[3 * q + 2]; }
+    const float lse = M + logf(S);
+    p.lse[r] = lse;
+    local += d - lse;
+  }
+  local = wave_sum_all(local);
+  if ((threadIdx.x & 63) == 0) atomicAdd(p.nce_sum, local);
 }
 
 // Backward on the matrix cores, one workgroup per step i (pred_i staged once), looping over 32-row blocks:
@@ -165,14 +197,15 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
     p.denc += (long long)p.t0_dev[0] * p.s_i;
   }
   const int i = blockIdx.x;
-  const int B = p.B, Bc = p.Bc, C = p.C, PS = C | 1, DS = Bc | 1;
+  const int col0 = blockIdx.y * CPC_PANEL;         // this workgroup's column panel
+  const int B = p.B, Bc = min(CPC_PANEL, p.Bc - col0), C = p.C, PS = C | 1, DS = Bc | 1;
   const int nct = (C + 31) / 32, ntiles = (Bc + 31) / 32;
   float* predl = lds;                              // [Bc][PS]
   float* encl = predl + (size_t)Bc * PS;           // [32][PS]
   float* dtl = encl + 32 * PS;                     // [32][DS]
   float* part = dtl + 32 * DS;                     // [4 waves][32][32]  partial denc tiles of one channel tile
   float* lsel = part + 4 * 32 * 32;                // [32]
-  const float* predg = p.pred + (long long)i * Bc * C;
+  const float* predg = p.pred + ((long long)i * p.Bc + col0) * C;
   for (int idx = threadIdx.x; idx < Bc * C; idx += 256) {
     const int j = idx / C, c = idx - j * C;
     predl[j * PS + c] = predg[idx];
@@ -224,7 +257,7 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
           const int b = r0 + row;
           float v = 0.f;
-          if (col_ok && b < B) v = (expf(acc[t][r] - lsel[row]) - (j == b + p.col_off ? 1.f : 0.f)) * gs;
+          if (col_ok && b < B) v = (expf(acc[t][r] - lsel[row]) - (col0 + j == b + p.col_off ? 1.f : 0.f)) * gs;
           acc[t][r] = v;
           if (ct0 == 0 && col_ok) dtl[row * DS + j] = v;            // for (3), first channel pass only
         }
@@ -267,8 +300,11 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
           for (int o = threadIdx.x; o < 32 * 32; o += 256) {
             const int row = o >> 5, cc = ct * 32 + (o & 31);
             const int b = r0 + row;
-            if (b < B && cc < C)
-              p.denc[i * p.s_i + b * p.s_b + cc * p.s_c] = (part[o] + part[1024 + o]) + (part[2048 + o] + part[3072 + o]);
+            if (b < B && cc < C) {
+              const float v = (part[o] + part[1024 + o]) + (part[2048 + o] + part[3072 + o]);
+              float* dst = p.denc + (i * p.s_i + b * p.s_b + cc * p.s_c);
+              if (p.n_panels == 1) *dst = v; else atomicAdd(dst, v);      // panels: the caller zero-fills denc
+            }
           }
         }
       }
@@ -285,7 +321,7 @@ __global__ __launch_bounds__(256) void cpc_bwd_kernel(CpcParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = (wave + 4 * t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (j < Bc) p.dpred[((long long)i * Bc + j) * C + c] = dP[t][u][r];
+          if (j < Bc) p.dpred[((long long)i * p.Bc + col0 + j) * C + c] = dP[t][u][r];
         }
       }
     }
@@ -300,17 +336,26 @@ static int cpc_check(const CpcParams& p, size_t lds_bytes, const char* who) {
   return 0;
 }
 
+extern "C" int64_t fst_cpc_workspace_floats(int T, int B, int Bc) {
+  const int np = (Bc + CPC_PANEL - 1) / CPC_PANEL;
+  return np > 1 ? (int64_t)T * B * np * 3 : 0;
+}
+
 extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev,
                                const float* pred, int T, int B, int C, int Bc, int col_off, float* lse, float* nce_sum,
-                               void* stream) {
+                               float* ws, void* stream) {
   CpcParams p = {};
   p.t0_dev = t0_dev;
   p.enc = enc; p.s_i = s_i; p.s_b = s_b; p.s_c = s_c; p.pred = pred; p.lse = lse; p.nce_sum = nce_sum;
   p.T = T; p.B = B; p.C = C; p.Bc = Bc; p.col_off = col_off;
-  const size_t lds_bytes = ((size_t)Bc * (C | 1) + 32 * (C | 1) + 3 * 4 * 32) * sizeof(float);
+  const int Bp = Bc < CPC_PANEL ? Bc : CPC_PANEL;
+  p.n_panels = (Bc + CPC_PANEL - 1) / CPC_PANEL;
+  p.ws = ws;
+  const size_t lds_bytes = ((size_t)Bp * (C | 1) + 32 * (C | 1) + 3 * 4 * 32) * sizeof(float);
   if (int rc = cpc_check(p, lds_bytes, "fst_cpc_nce_fwd")) return rc;
   FST_REQUIRE(nce_sum, "fst_cpc_nce_fwd: nce_sum is null");
-  FST_REQUIRE(Bc <= 128 * CPC_MAXTILES, "fst_cpc_nce_fwd: %d > %d negatives (columns) not supported yet", Bc, 128 * CPC_MAXTILES);
+  FST_REQUIRE(p.n_panels == 1 || ws, "fst_cpc_nce_fwd: %d columns = %d panels need the workspace (fst_cpc_workspace_floats)", Bc,
+              p.n_panels);
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)cpc_fwd_kernel, "fst_cpc_nce_fwd")) return rc;
   // pred_i is staged once per workgroup; ~512 workgroups: split the row blocks of a step only as far as that needs
@@ -318,8 +363,14 @@ extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64
   int ysplit = (512 + T - 1) / T;
   if (ysplit > row_blocks) ysplit = row_blocks;
   if (ysplit < 1) ysplit = 1;
-  hipLaunchKernelGGL(cpc_fwd_kernel, dim3(T, ysplit), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(cpc_fwd_kernel, dim3(T, ysplit, p.n_panels), dim3(256), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
+  if (p.n_panels > 1) {
+    long long blocks = ((long long)T * B + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(cpc_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    FST_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -330,14 +381,15 @@ extern "C" int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64
   p.t0_dev = t0_dev;
   p.enc = enc; p.s_i = s_i; p.s_b = s_b; p.s_c = s_c; p.pred = pred; p.lse = const_cast<float*>(lse);
   p.gout = gout; p.denc = denc; p.dpred = dpred; p.T = T; p.B = B; p.C = C; p.Bc = Bc; p.col_off = col_off;
-  const size_t lds_bytes = ((size_t)Bc * (C | 1) + 32 * (C | 1) + 32 * (size_t)(Bc | 1) + 4 * 32 * 32 + 32) * sizeof(float);
+  const int Bp = Bc < CPC_PANEL ? Bc : CPC_PANEL;
+  p.n_panels = (Bc + CPC_PANEL - 1) / CPC_PANEL;
+  const size_t lds_bytes = ((size_t)Bp * (C | 1) + 32 * (C | 1) + 32 * (size_t)(Bp | 1) + 4 * 32 * 32 + 32) * sizeof(float);
   if (int rc = cpc_check(p, lds_bytes, "fst_cpc_nce_bwd")) return rc;
   FST_REQUIRE(gout && denc && dpred, "fst_cpc_nce_bwd: null gradient buffer");
-  FST_REQUIRE(Bc <= 128 * CPC_MAXTILES, "fst_cpc_nce_bwd: %d > %d negatives (columns) not supported yet", Bc, 128 * CPC_MAXTILES);
   FST_REQUIRE(C <= 32 * CPC_CT_MAX, "fst_cpc_nce_bwd: C=%d > %d not supported yet", C, 32 * CPC_CT_MAX);
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)cpc_bwd_kernel, "fst_cpc_nce_bwd")) return rc;
-  hipLaunchKernelGGL(cpc_bwd_kernel, dim3(T), dim3(256), lds_bytes, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(cpc_bwd_kernel, dim3(T, p.n_panels), dim3(256), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }

@@ -217,10 +217,15 @@ int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, con
  * Rows (B encodings of this rank) and columns (Bc predictions) may differ: "global batch" data parallelism scores
  * the local rows against the predictions gathered from every rank, the positives at columns col_off + b.
  * ------------------------------------------------------------------------------------------- */
+/* More than 256 columns are processed as panels of 256: the forward then needs a workspace of
+ * fst_cpc_workspace_floats(T, B, Bc) floats (0 for Bc <= 256) for the per-panel softmax statistics, and the backward
+ * accumulates denc across panels with fp32 atomics (the caller zero-fills denc — it must anyway outside [t0, t0+T)). */
+int64_t fst_cpc_workspace_floats(int T, int B, int Bc);
 int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
                     const float* pred /* [T][Bc][C] */, int T, int B, int C,
                     int Bc /* columns = negatives; = B on one GPU */, int col_off /* column of row 0's positive */,
-                    float* lse /* [T][B] */, float* nce_sum /* scalar, zeroed */, void* stream);
+                    float* lse /* [T][B] */, float* nce_sum /* scalar, zeroed */, float* workspace /* NULL if Bc <= 256 */,
+                    void* stream);
 int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
                     const float* pred, const float* lse, int T, int B, int C, int Bc, int col_off, const float* gout,
                     float* denc /* same strides as enc */, float* dpred /* [T][Bc][C] */, void* stream);

@@ -271,7 +271,9 @@ def test_cpc_nce(B, C, L, T, t0):
     assert_close(fd.grad, feat.grad, 5e-5, "dfeat"); assert_close(pd.grad, pred.grad, 5e-5, "dpred")
 
 
-@pytest.mark.parametrize("B,Bc,off,C,L,T,t0", [(4, 12, 4, 6, 20, 10, 3), (37, 111, 74, 50, 128, 64, 9), (64, 256, 128, 50, 512, 256, 7)])
+@pytest.mark.parametrize("B,Bc,off,C,L,T,t0", [(4, 12, 4, 6, 20, 10, 3), (37, 111, 74, 50, 128, 64, 9), (64, 256, 128, 50, 512, 256, 7),
+                                               (64, 2048, 1792, 50, 512, 256, 7),      # 8 ranks x 256: eight column panels
+                                               (40, 300, 259, 50, 128, 64, 3), (256, 512, 256, 50, 512, 32, 100)])   # ragged last panel
 def test_cpc_nce_rows_against_gathered_columns(B, Bc, off, C, L, T, t0):
     """Global-batch data parallelism: B local rows scored against Bc gathered predictions, positives at column off+b."""
     g = torch.Generator().manual_seed(B + Bc)
@@ -445,7 +447,7 @@ def test_weight_gradient_with_product_operand(arithmetic):
     """res_skip weight gradient with x = t·s formed while staging (x0 = the t rows of the saved [B, 2n, L] gate halves,
     x0_mul_off = n·L to the s rows) equals the gradient against a materialised acts tensor."""
     g = torch.Generator().manual_seed(77)
-    for n, B, L, M in ((120, 2, 512, 240), (8, 3, 40, 8), (33, 2, 132, 66)):
+    for n, B, L, M in ((120, 2, 512, 240), (8, 3, 40, 8), (34, 2, 132, 68), (33, 2, 132, 33)):
         ts = torch.randn(B, 2 * n, L, generator=g, dtype=torch.float64)
         dy = torch.randn(B, M, L, generator=g, dtype=torch.float64)
         acts = ts[:, :n] * ts[:, n:]
