@@ -826,8 +826,9 @@ class WNFn(torch.autograd.Function):
         for i in reversed(range(nl)):
             last = i == nl - 1
             # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
-            dacts = None if ctx.fused else torch.empty(B, n, L, device=dev, dtype=torch.float32)
-            if ctx.fused:
+            fused_bwd = ctx.fused and os.environ.get("FST_WN_BWD", "fused") == "fused"      # diagnostics: =unfused
+            dacts = None if fused_bwd else torch.empty(B, n, L, device=dev, dtype=torch.float32)
+            if fused_bwd:
                 pass
             elif last:
                 bf3 = bf3_ok(S.rs_T_last, L)
@@ -843,6 +844,8 @@ class WNFn(torch.autograd.Function):
                 # fused forward: acts = t·s is re-formed from the saved halves (rows [0,n) and [n,2n) of ts) while staging
                 x_rs = ts_list[i][:, :n] if ctx.fused else acts_list[i]
                 mul = n * L if ctx.fused else 0
+                if ctx.fused and os.environ.get("FST_WN_PROD", "1") == "0":                   # diagnostics: materialise acts
+                    x_rs, mul = (ts_list[i][:, :n] * ts_list[i][:, n:]).contiguous(), 0
                 if last:
                     d_rs_w[i], _ = S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul)
                     d_rs_b[i] = d_out_sum
@@ -851,7 +854,7 @@ class WNFn(torch.autograd.Function):
                     d_rs_b[i] = torch.cat([row_sum(d_a), d_out_sum])
             # ---- through the gate
             dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
-            if ctx.fused:
+            if fused_bwd:
                 wn_layer_bwd(None if last else d_a, d_out, ts_list[i], wn_pack_bwd(rs_w[i], n, last), dg, last, n)
             else:
                 check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]),

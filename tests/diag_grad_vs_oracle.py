@@ -13,11 +13,18 @@ from oracle import restatement as R
 from test_gpu_full_step import _pair, _trainer_from, _step_both
 
 L, B, seed = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 512), (2, 4), (3, 512)))
-js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=seed, dropout_p=0.0, zero_end=False)
-tr = _trainer_from(js, L, L, 4)
-gen = torch.Generator().manual_seed(seed + 1)
-batch = (_pair(gen, B, 1, L, 4), _pair(gen, B, 1, L, 4))
-rep_o, want, rep, grads = _step_both(js, tr, batch, (L // 8, L // 16))
+if seed == 100:                                              # the four-source test's first pipeline
+    js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=100, dropout_p=0.0, zero_end=False)
+    tr = _trainer_from(js, L, L, 4)
+    gen = torch.Generator().manual_seed(2024)
+    target = _pair(gen, B, 1, L, 4)
+    batch, ts = (target, _pair(gen, B, 1, L, 4)), (17, 40)
+else:
+    js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=seed, dropout_p=0.0, zero_end=False)
+    tr = _trainer_from(js, L, L, 4)
+    gen = torch.Generator().manual_seed(seed + 1)
+    batch, ts = (_pair(gen, B, 1, L, 4), _pair(gen, B, 1, L, 4)), (L // 8, L // 16)
+rep_o, want, rep, grads = _step_both(js, tr, batch, ts)
 print("MATH", ops.MATH)
 for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s"):
     print(f"  loss {k:9s} {float(rep[k]):+.6e} oracle {float(rep_o[k]):+.6e} rel {abs(float(rep[k]) - float(rep_o[k])) / max(1, abs(float(rep_o[k]))):.1e}")
@@ -31,3 +38,5 @@ for name in tr.MODULES:
         worst.append((err / scale, l2, k))
     worst.sort(reverse=True)
     print(f"{name:13s} scale {scale:.3e}  worst: " + "; ".join(f"{k} {e:.1e} (L2 {l:.1e})" for e, l, k in worst[:3]))
+if os.environ.get("DIAG_DUMP"):
+    torch.save({f"{m}.{k}": v.detach().cpu() for m in grads for k, v in grads[m].items()}, os.environ["DIAG_DUMP"])

