@@ -75,16 +75,18 @@ def eval_accuracy(feature_extraction_module, classification_module, batches: Ite
     predictions kept on the device and one host read at the end.  The modules must already be in eval mode, as the
     reference puts them before calling (train_and_test.py:175-176); ``feature_trans`` is the source side's
     DimensionUnification.  Returns (accuracy, predictions)."""
+    from . import ops
     dev = next(classification_module.parameters()).device
     preds, hits, n = [], torch.zeros((), device=dev, dtype=torch.int64), 0
-    for x, y in batches:
-        f = feature_extraction_module(x.float().to(dev))
-        if feature_trans is not None:
-            f = feature_trans(f)
-        p = classification_module(f)[0].argmax(dim=1)
-        preds.append(p)
-        hits += (p == y.to(dev)).sum()
-        n += int(y.numel())
+    with ops.pack_cache():            # eval-mode BatchNorm folded into the convs; packed weight images shared by all batches
+        for x, y in batches:
+            f = feature_extraction_module(x.float().to(dev))
+            if feature_trans is not None:
+                f = feature_trans(f)
+            p = classification_module(f)[0].argmax(dim=1)
+            preds.append(p)
+            hits += (p == y.to(dev)).sum()
+            n += int(y.numel())
     if n == 0:
         raise ValueError("eval_accuracy: no samples")
     return float(hits.item()) / n, torch.cat(preds)

@@ -78,10 +78,48 @@ class build_layer_with_layer_parameter(nn.Module):
         return ops.conv1d(self.spec, X.contiguous(), self.conv1d.weight, self.conv1d.bias)
 
     def forward(self, X: torch.Tensor, defer_bn: bool = False) -> torch.Tensor:
+        if not defer_bn and inference_mode(self.bn):
+            return self.forward_folded(X)
         y = self.conv(X)
         if defer_bn:
             return y
         return batch_norm_act(y, self.bn, self.relu_or_not_at_last_layer)
+
+    def forward_folded(self, X: torch.Tensor, res: Optional[torch.Tensor] = None, relu: Optional[bool] = None) -> torch.Tensor:
+        """Inference: conv, BatchNorm (running statistics), optional residual add and ReLU in ONE launch — the
+        normalisation is folded into the weights and the bias, the rest is the conv engine's epilogue."""
+        lo, hi = self._live(X.device)
+        ops.mask_taps_(self.conv1d.weight.data, lo, hi)                      # the reference re-masks in eval mode too
+        if not hasattr(self, "_fold"):
+            self._fold = _FoldedBN()
+        w, b = self._fold.get(self.conv1d, self.bn)
+        relu = self.relu_or_not_at_last_layer if relu is None else relu
+        return self.spec.forward(X.contiguous(), None, w, None, b, res=res, flags=ops.EPI_RELU if relu else 0)
+
+
+def inference_mode(*bns: nn.BatchNorm1d) -> bool:
+    """Eval-mode BatchNorm with autograd off (the eval pass of utils.py:27-183, the K-way forward of
+    multi_source_voting.py:283-291): the normalisation is an affine map per channel that folds into the conv."""
+    return (not torch.is_grad_enabled()) and all(not bn.training for bn in bns)
+
+
+class _FoldedBN:
+    """conv → eval-mode BatchNorm as ONE conv:  W' = W·γ/√(σ²+ε),  b' = (b − μ)·γ/√(σ²+ε) + β.  Cached on the version
+    counters of the six tensors it is made of, so an eval loop folds once."""
+
+    def __init__(self):
+        self._key, self._wb = None, None
+
+    def get(self, conv: nn.Conv1d, bn: nn.BatchNorm1d):
+        src = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in src) + (bn.eps,)
+        if key != self._key:
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                self._wb = ((conv.weight * scale.view(-1, 1, 1)).contiguous(),
+                            ((conv.bias - bn.running_mean) * scale + bn.bias).contiguous())
+            self._key = key
+        return self._wb
 
 
 def batch_norm_act(y: torch.Tensor, bn: nn.BatchNorm1d, relu: bool) -> torch.Tensor:
@@ -148,7 +186,15 @@ class SampaddingConv1D_BN(nn.Module):
         return ops.conv1d(self.spec, X.contiguous(), self.conv1d.weight, self.conv1d.bias)
 
     def forward(self, X: torch.Tensor) -> torch.Tensor:
+        if inference_mode(self.bn):
+            return self.forward_folded(X)
         return batch_norm_act(self.conv(X), self.bn, False)
+
+    def forward_folded(self, X: torch.Tensor) -> torch.Tensor:
+        if not hasattr(self, "_fold"):
+            self._fold = _FoldedBN()
+        w, b = self._fold.get(self.conv1d, self.bn)
+        return self.spec.forward(X.contiguous(), None, w, None, b)
 
 
 class Res_OS_layer(nn.Module):
@@ -162,6 +208,13 @@ class Res_OS_layer(nn.Module):
         self.res = SampaddingConv1D_BN(layer_parameter_list[0][0][0], out_put_channel_numebr, 1)
 
     def forward(self, X: torch.Tensor) -> torch.Tensor:
+        if inference_mode(self.net.layer_list[-1].bn, self.res.bn):
+            # inference: shortcut conv+BN as one launch, then the block's last conv+BN + shortcut + ReLU as one launch
+            layers = self.net.layer_list
+            h = X
+            for layer in layers[:-1]:
+                h = layer(h)                                                 # folded: conv + BN + ReLU in one launch each
+            return layers[-1].forward_folded(h, res=self.res.forward_folded(X), relu=True)
         y_block = self.net(X, defer_last_bn=True)
         y_short = self.res.conv(X)
         bn_a, bn_b = self.net.layer_list[-1].bn, self.res.bn

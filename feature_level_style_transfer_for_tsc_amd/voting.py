@@ -51,14 +51,18 @@ def collect_logits(models: Sequence[Tuple[torch.nn.Module, torch.nn.Module]],
                    batches: Iterable[Tuple[torch.Tensor, torch.Tensor]]) -> Tuple[torch.Tensor, torch.Tensor]:
     """Eval-mode logits of K (feature extractor, classifier) pairs over the same batches: ([K, N, C], labels [N]),
     everything kept on the device (the loops at :283-291 / :370-404).  The modules must be in eval mode."""
+    from . import ops
     dev = next(models[0][1].parameters()).device
     per_model: List[List[torch.Tensor]] = [[] for _ in models]
     labels: List[torch.Tensor] = []
-    for x, y in batches:
-        x = x.float().to(dev)
-        labels.append(y.to(dev))
-        for k, (fe, clf) in enumerate(models):
-            per_model[k].append(clf(fe(x))[0])
+    # eval mode + no autograd: every conv → BatchNorm (→ add → ReLU) of the K pipelines is ONE launch with the
+    # normalisation folded into the weights (os_cnn._FoldedBN); the packed weight images are shared by all batches
+    with ops.pack_cache():
+        for x, y in batches:
+            x = x.float().to(dev)
+            labels.append(y.to(dev))
+            for k, (fe, clf) in enumerate(models):
+                per_model[k].append(clf(fe(x))[0])
     return torch.stack([torch.cat(v) for v in per_model]), torch.cat(labels)
 
 

@@ -125,6 +125,12 @@ def test_config2_four_sources_one_step_each_then_vote():
         batch = (target, _pair(gen, B, 1, L, ncls))
         _check_step(*_step_both(js, tr, batch, (17 + k, 40 - k)), tr, f"source {k}")
         fe, clf = tr.m["fe_t"], tr.m["clf_t"]
+        # one optimisation step leaves the BatchNorm running statistics at 0.9·init + 0.1·batch: eval-mode logits of such a
+        # model are in the hundreds, where the reference's own vote — exp(x)/Σexp(x) in float32 (multi_source_voting.py:407)
+        # — overflows to NaN.  Let the statistics settle (train-mode forwards, no parameter update) as an epoch would.
+        with torch.no_grad():
+            for _ in range(40):
+                clf(fe(target[0].to(DEV)))
         fe.eval(); clf.eval()
         models.append((fe, clf))
         oracle_params.append(({n: v.detach().cpu() for n, v in fe.state_dict().items()},
@@ -152,7 +158,7 @@ def test_full_batch_graph_replay_equals_eager_step():
     same snapshot — nine losses, logits, GradNorm weights, and the post-step state of parameters with real gradients."""
     B, L = 256, 512
     torch.manual_seed(1234)
-    tr = fst.JointTrainer(fst.JointConfig(L_t=L, L_s=L, nf_end_std=0.05), DEV)
+    tr = fst.JointTrainer(fst.JointConfig(L_t=L, L_s=L, dropout_p=0.0), DEV)  # the bench configuration, dropout off (its masks are drawn per call)
     gen = torch.Generator().manual_seed(7)
     (x_t, y_t), (x_s, y_s) = _pair(gen, B, 1, L, 4), _pair(gen, B, 1, L, 4)
     args = (x_t.to(DEV), y_t.to(DEV), x_s.to(DEV), y_s.to(DEV))

@@ -450,3 +450,46 @@ def test_device_loader_pinned_async_copies():
         assert xb.shape == (8, 3, 64) and yb.shape == (8,)
         n += 8
     assert n == 32 and len(sh) == 4
+
+
+def test_inference_mode_folds_batchnorm_into_the_convs():
+    """Eval mode with autograd off (the eval pass and the K-way voting forward): every conv → BatchNorm (→ residual add
+    → ReLU) runs as ONE launch with the normalisation folded into weights and bias.  Same logits as the unfolded eval
+    path (autograd on) and as the oracle; a third of the conv-engine + BatchNorm launches."""
+    g = load("joint_small")
+    meta = json.loads(str(g["meta"]))
+    tup = lambda lp: [[tuple(t) for t in l] for l in lp]
+    fe, clf = fst.OS_CNN_res(tup(meta["lp_t"])).to(DEV), fst.OS_CNN(tup(meta["lp_clf"]), meta["ncls_t"]).to(DEV)
+    Pf, Pc = tsd(sub(g, "sd0.fe_t.")), tsd(sub(g, "sd0.clf_t."))
+    gen = torch.Generator().manual_seed(5)
+    for P in (Pf, Pc):                                                    # non-trivial running statistics
+        for k in P:
+            if k.endswith("running_mean"):
+                P[k] = torch.randn(P[k].shape, generator=gen) * 0.3
+            if k.endswith("running_var"):
+                P[k] = torch.rand(P[k].shape, generator=gen) + 0.5
+    fe.load_state_dict(Pf); clf.load_state_dict(Pc)
+    fe.eval(); clf.eval()
+    x = torch.randn(6, meta["C_in_t"], meta["L_t"], generator=gen)
+    logits_unfolded, pooled_unfolded = clf(fe(x.to(DEV)))                  # autograd on: BatchNorm kernels in eval mode
+    with torch.no_grad():
+        logits, pooled = clf(fe(x.to(DEV)))                                # folded
+        again, _ = clf(fe(x.to(DEV)))                                      # cached fold
+    want, want_pooled = R.classifier(R.feature_extractor(x, Pf, tup(meta["lp_t"]), False), Pc, tup(meta["lp_clf"]), False)
+    close(logits, want, 1e-4, "folded logits vs oracle"); close(pooled, want_pooled, 1e-4, "folded pooled vs oracle")
+    close(logits, logits_unfolded, 2e-5, "folded vs unfolded eval path")
+    assert torch.equal(again, logits)
+    # the fold follows the parameters: change a running statistic in place -> the next inference call sees it
+    with torch.no_grad():
+        clf.layer_list[0].bn.running_mean.add_(0.25)
+        moved, _ = clf(fe(x.to(DEV)))
+    Pc2 = dict(Pc); Pc2["net.0.bn.running_mean"] = Pc["net.0.bn.running_mean"] + 0.25
+    want2, _ = R.classifier(R.feature_extractor(x, Pf, tup(meta["lp_t"]), False), Pc2, tup(meta["lp_clf"]), False)
+    close(moved, want2, 1e-4, "logits after moving a running mean")
+    # launches: timer keys count conv-engine launches; folded = 7 convs (3 + shortcut + 3), nothing else from this library
+    timer = ops.KernelTimer()
+    ops.KERNEL_TIMER = timer
+    with torch.no_grad():
+        clf(fe(x.to(DEV)))
+    ops.KERNEL_TIMER = None
+    assert sum(v["launches"] for v in timer.summary().values()) == 7
