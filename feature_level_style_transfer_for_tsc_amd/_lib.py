@@ -49,6 +49,7 @@ _SIGNATURES = {
     "fst_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_gate_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_coupling_sum_slots": (c_int64, [c_int, c_int, c_int]),
     "fst_coupling_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, _P, c_void_p]),
     "fst_coupling_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_coupling_inv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
@@ -60,6 +61,8 @@ _SIGNATURES = {
     "fst_wn_bwd_image_bytes": (c_int64, [c_int, c_int]),
     "fst_wn_pack_bwd": (c_int, [_P, c_int, c_int, _P, c_int64, c_void_p]),
     "fst_wn_layer_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_gru_fwd": (c_int, [_P, _P, _P, _P, _P, _I32P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_gru_bwd": (c_int, [_P, _P, _P, _P, _I32P, c_int, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_axpy": (c_int, [_P, _P, c_float, c_int64, c_void_p]),
     "fst_add_slices": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_void_p]),
     "fst_cpc_workspace_floats": (c_int64, [c_int, c_int, c_int]),

@@ -59,15 +59,21 @@ class CPC(nn.Module):
         B, C, L = features.shape
         T = self.timestep
         z = features.transpose(1, 2)
-        if isinstance(t_samples, torch.Tensor):
-            output, _ = self.gru(z[:, : max(1, T // 2), :].contiguous())
+        dev_t = isinstance(t_samples, torch.Tensor)
+        S = max(1, T // 2) if dev_t else t_samples + 1          # device index: static shapes, the recurrence stops at t
+        if self.hidden_dim == 64 and features.is_cuda:
+            # the input projections of all S steps as one GEMM, then the recurrence as ONE persistent launch
+            # (ops.GRULastFn) — nn.GRU's parameters are used as they are (torch's r | z | n gate order)
+            xproj = torch.matmul(z[:, :S, :], self.gru.weight_ih_l0.t()) + self.gru.bias_ih_l0
+            c_t = ops.GRULastFn.apply(xproj, self.gru.weight_hh_l0, self.gru.bias_hh_l0, t_samples)
+        elif dev_t:
+            output, _ = self.gru(z[:, :S, :].contiguous())
             idx = t_samples.long().view(1, 1, 1).expand(B, 1, self.hidden_dim)
             c_t = output.gather(1, idx).reshape(B, self.hidden_dim)
-            t0 = (t_samples + 1).to(torch.int32)
         else:
-            output, _ = self.gru(z[:, : t_samples + 1, :].contiguous())
+            output, _ = self.gru(z[:, :S, :].contiguous())
             c_t = output[:, t_samples, :].reshape(B, self.hidden_dim)
-            t0 = t_samples + 1
+        t0 = (t_samples + 1).to(torch.int32) if dev_t else t_samples + 1
         W, b = self._stacked()
         pred = torch.baddbmm(b.unsqueeze(1), c_t.unsqueeze(0).expand(T, B, -1), W.transpose(1, 2))   # [T, B, C]
         # global-batch data parallelism: the negatives of a row are the predictions of EVERY rank's samples

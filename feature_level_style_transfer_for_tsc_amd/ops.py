@@ -887,11 +887,11 @@ class CouplingFn(torch.autograd.Function):
         u, o = u.contiguous(), o.contiguous()
         B, C, L = u.shape
         xn = torch.empty_like(u)
-        sums = torch.zeros(2, device=u.device, dtype=torch.float32)
-        check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, _same_numel(u, o, xn), ptr(sums), stream_ptr()),
+        part = torch.empty(lib.fst_coupling_sum_slots(B, C // 2, L), 2, device=u.device, dtype=torch.float32)
+        check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, _same_numel(u, o, xn), ptr(part), stream_ptr()),
               "fst_coupling_fwd")
         ctx.save_for_backward(u, o)
-        return xn, sums
+        return xn, part.sum(dim=0)
 
     @staticmethod
     def backward(ctx, dxn, dsums):
@@ -977,6 +977,57 @@ class CPCNceFn(torch.autograd.Function):
                                   pred.size(1), ctx.col_off, ptr(g), dfeat.data_ptr() + 4 * t0, ptr(dpred), stream_ptr()),
               "fst_cpc_nce_bwd")
         return dfeat, dpred, None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# GRU recurrence (CPC context network)
+# --------------------------------------------------------------------------------------------------
+class GRULastFn(torch.autograd.Function):
+    """h_{t_last} of a one-layer GRU with h0 = 0 given the input projections of every step.
+
+    ``xproj`` [B, S, 3H] = x_t·W_ihᵀ + b_ih (torch's gate order r | z | n); ``t_last`` is a Python int or a 0-d int32
+    DEVICE tensor (a captured hipGraph varies it between replays).  Forward and backward are ONE persistent launch each
+    (csrc/gru.hip) instead of MIOpen's ~10 launches per time step; the weight gradients of the recurrent matrix are two
+    small GEMMs over the saved per-step gate gradients."""
+
+    @staticmethod
+    def forward(ctx, xproj: Tensor, w_hh: Tensor, b_hh: Tensor, t_last):
+        lib = _lib.load()
+        _lib.require_gpu_tensor(xproj, "xproj")
+        xproj, w_hh, b_hh = xproj.contiguous(), w_hh.contiguous(), b_hh.contiguous()
+        B, S, H3 = xproj.shape
+        H = H3 // 3
+        t_dev = t_last if isinstance(t_last, torch.Tensor) else None
+        t_host = 0 if t_dev is not None else int(t_last)
+        assert t_dev is None or (t_dev.dtype == torch.int32 and t_dev.is_cuda)
+        h_all = torch.zeros(B, S, H, device=xproj.device, dtype=torch.float32)
+        gates = torch.empty(B, S, 4 * H, device=xproj.device, dtype=torch.float32)
+        check(lib.fst_gru_fwd(ptr(xproj), ptr(w_hh), ptr(b_hh), ptr(h_all), ptr(gates), ptr(t_dev), t_host, B, S, H, h_all.numel(),
+                              stream_ptr()), "fst_gru_fwd")
+        if t_dev is not None:
+            h_t = h_all.gather(1, t_dev.long().view(1, 1, 1).expand(B, 1, H)).reshape(B, H)
+        else:
+            h_t = h_all[:, t_host, :].contiguous()
+        ctx.save_for_backward(w_hh, h_all, gates)
+        ctx.t_dev, ctx.t_host = t_dev, t_host
+        return h_t
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        w_hh, h_all, gates = ctx.saved_tensors
+        B, S, H = h_all.shape
+        dxproj = torch.zeros(B, S, 3 * H, device=dh.device, dtype=torch.float32)
+        dgh = torch.zeros(B, S, 3 * H, device=dh.device, dtype=torch.float32)
+        check(lib.fst_gru_bwd(ptr(w_hh), ptr(h_all), ptr(gates), ptr(dh.contiguous()), ptr(ctx.t_dev), ctx.t_host, ptr(dxproj),
+                              ptr(dgh), B, S, H, h_all.numel(), stream_ptr()), "fst_gru_bwd")
+        d_w = d_b = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # dW_hh = Σ_{b,s} dgh[b,s] ⊗ h[b,s−1]  (h_{−1} = 0; steps beyond t_last carry zeros in dgh)
+            g2 = dgh[:, 1:, :].reshape(-1, 3 * H)
+            d_w = g2.t() @ h_all[:, :-1, :].reshape(-1, H) if S > 1 else torch.zeros_like(w_hh)
+            d_b = dgh.sum(dim=(0, 1))
+        return dxproj, d_w, d_b, None
 
 
 # --------------------------------------------------------------------------------------------------

@@ -159,8 +159,9 @@ int fst_gate_fwd(float* g_ts, float* acts, int B, int n, int L, int64_t numel_ac
 /* dg[:n] = dacts·s·(1−t²), dg[n:] = dacts·t·s·(1−s) */
 int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, int L, int64_t numel_acts, void* stream);
 /* affine coupling (:173-178): xn[:, :h]=u[:, :h]; xn[:, h:] = exp(o[:, h:])·u[:, h:] + o[:, :h].
- * sums (optional float[2], accumulated): sums[0] += Σ log_s (= Σ o[:, h:]), sums[1] += Σ xn² — the full-tensor reductions of
- * WaveGlowLoss (Simplified_NF_WaveGlow.py:230-241) taken in the same pass. */
+ * sums (optional float[fst_coupling_sum_slots(B, h, L)][2], written): per-workgroup partials (Σ log_s, Σ xn²) — the
+ * full-tensor reductions of WaveGlowLoss (Simplified_NF_WaveGlow.py:230-241) taken in the same pass; the caller adds the slots. */
+int64_t fst_coupling_sum_slots(int B, int h, int L);
 int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int64_t numel, float* sums, void* stream);
 /* backward of the above given dxn (may be NULL = 0) and (added) d_logs; gsums (optional DEVICE float[2]) = the cotangents of
  * the two sums: dxn_eff = dxn + 2·gsums[1]·xn, d log_s += gsums[0]; writes du (full 2h channels) and do */
@@ -229,6 +230,21 @@ int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, con
 int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
                     const float* pred, const float* lse, int T, int B, int C, int Bc, int col_off, const float* gout,
                     float* denc /* same strides as enc */, float* dpred /* [T][Bc][C] */, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GRU recurrence of the CPC context network (Comparison/SLARDA/train.py:65-67: nn.GRU(C, 64, batch_first=True), h0 = 0),
+ * one persistent launch per direction.  xproj [B][S][3H] = x_t·W_ihᵀ + b_ih for every step (gate order r | z | n, torch's);
+ * the kernel runs steps 0..t_last (t_last_dev: optional DEVICE scalar, read instead of t_last so a captured graph can vary
+ * it), saves h_all [B][S][H] and gates [B][S][4H] = (r, z, n, W_hn·h + b_hn).  Only h at step t_last is consumed by CPC.
+ * Backward: dout [B][H] = d loss / d h_{t_last}; writes dxproj [B][S][3H] (→ d input, dW_ih, db_ih by GEMMs outside) and
+ * dgh [B][S][3H] (dW_hh = Σ dgh ⊗ h_{t−1}, db_hh = Σ dgh); both must be zero-filled by the caller (steps > t_last stay 0).
+ * H = 64 only.  numel_h = element count of h_all as the caller holds it.
+ * ------------------------------------------------------------------------------------------- */
+int fst_gru_fwd(const float* xproj, const float* w_hh, const float* b_hh, float* h_all, float* gates,
+                const int32_t* t_last_dev, int t_last, int B, int S, int H, int64_t numel_h, void* stream);
+int fst_gru_bwd(const float* w_hh, const float* h_all, const float* gates, const float* dout,
+                const int32_t* t_last_dev, int t_last, float* dxproj, float* dgh, int B, int S, int H,
+                int64_t numel_h, void* stream);
 
 #ifdef __cplusplus
 }

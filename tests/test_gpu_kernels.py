@@ -460,3 +460,29 @@ def test_weight_gradient_with_product_operand(arithmetic):
         else:
             dw, _ = spec.grad_w(tsd[:, :n], None, dy.float().to(DEV), x0_mul_off=n * L)
         assert_close(dw[:, :, 0], want, 1e-4, f"dW with product operand n={n}")
+
+
+@pytest.mark.parametrize("B,S,C,t_last,dev_index", [(5, 9, 7, 8, False), (256, 128, 50, 77, True), (33, 40, 50, 0, False),
+                                                    (64, 128, 50, 127, True), (3, 1, 4, 0, False)])
+def test_gru_recurrence_matches_torch_gru(B, S, C, t_last, dev_index):
+    """ops.GRULastFn (input projection GEMM outside, the recurrence as one persistent launch each way) against
+    torch.nn.GRU in float64 on the CPU: h at step t_last, gradients of the input and of all four parameter tensors."""
+    H = 64
+    torch.manual_seed(B * 100 + S)
+    gru = torch.nn.GRU(C, H, num_layers=1, batch_first=True).double()
+    x = torch.randn(B, S, C, dtype=torch.float64, requires_grad=True)
+    r = torch.randn(B, H, dtype=torch.float64)
+    out, _ = gru(x)
+    (out[:, t_last] * r).sum().backward()
+    f = lambda t: t.detach().float().to(DEV).requires_grad_(True)
+    xd, w_ih, w_hh, b_ih, b_hh = f(x), f(gru.weight_ih_l0), f(gru.weight_hh_l0), f(gru.bias_ih_l0), f(gru.bias_hh_l0)
+    xproj = torch.matmul(xd, w_ih.t()) + b_ih
+    t_arg = torch.tensor(t_last, dtype=torch.int32, device=DEV) if dev_index else t_last
+    h = ops.GRULastFn.apply(xproj, w_hh, b_hh, t_arg)
+    (h * r.float().to(DEV)).sum().backward()
+    assert_close(h, out[:, t_last], 2e-5, "h_t")
+    assert_close(xd.grad, x.grad, 5e-5, "dx")
+    for got, want, name in ((w_ih, gru.weight_ih_l0, "dW_ih"), (w_hh, gru.weight_hh_l0, "dW_hh"), (b_ih, gru.bias_ih_l0, "db_ih"),
+                            (b_hh, gru.bias_hh_l0, "db_hh")):
+        assert_close(got.grad, want.grad, 5e-5, name)
+    assert float(xd.grad[:, t_last + 1:].abs().max()) == 0.0 if t_last + 1 < S else True      # steps beyond t_last: no gradient
