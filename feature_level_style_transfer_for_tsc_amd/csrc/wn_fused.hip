@@ -165,6 +165,9 @@ extern "C" int fst_wn_pack(const float* in_w, const float* cond_w, const float* 
 #ifndef WN_EXP
 #define WN_EXP 0
 #endif
+#ifndef WN_INTERLEAVE
+#define WN_INTERLEAVE 1      // LDS-DMA pieces of stage k+2 issued between the MFMA triples of stage k (0: all up front)
+#endif
 
 #ifdef FST_STAMPS
 // Diagnostic build only (tools/build_stamps.sh): per-phase s_memtime sums of the fused forward kernel, lane 0 of every wave.
@@ -305,57 +308,70 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
 
   // LDS-DMA of stage k into ring slot `slot`.  GEMM-1 stages: pieces [0, NA) are A, the rest the B sub-tiles
   // (8 channels × 32 samples of the 16-byte aligned, tap-shifted window); GEMM-2 k-steps: A only.
-  auto issue = [&](int k, int slot) {
-    char* const sl = ldsb + slot * WN_SLOT;
-    const char* asrc = p.img + (long long)k * WN_A_BYTES;
-    if (k >= S1) {
-      const int a0 = p.last ? 8 : 0;                 // last layer: only the skip-row blocks exist
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = a0 + wave_s + 4 * i;
-        if (idx < NA)
-          __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((WN_EXP & 4) ? zero16 : asrc + idx * 1024 + lane * 16),
-                                           WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
-      }
-      return;
-    }
+  // One stage's LDS-DMA, described by wave-uniform scalars (stage_src) and issued piece by piece (issue_piece: piece i of
+  // this wave is ring piece wave + 4i).  GEMM-1 stages: pieces [0, NA) are A, the rest the B sub-tiles (8 channels × 32
+  // samples of the 16-byte aligned, tap-shifted window); GEMM-2 k-steps: A only.
+  struct StageSrc {
+    char* sl;
+    const char* asrc;
     const float* xb;
-    int c_count, ones_row, shift;
+    int c_count, ones_row, t4, a0;
+    bool spill, gemm2;
+  };
+  auto stage_src = [&](int k, int slot) {
+    StageSrc ss;
+    ss.sl = ldsb + slot * WN_SLOT;
+    ss.asrc = p.img + (long long)k * WN_A_BYTES;
+    ss.gemm2 = k >= S1;
+    ss.a0 = p.last ? 8 : 0;                            // last layer: only the skip-row blocks of GEMM 2 exist
+    int shift = 0;
     if (k < 3 * CH) {
       const int tap = k / CH, c = k - tap * CH;
-      xb = ab + (long long)(16 * c) * L;
-      c_count = min(16, n - 16 * c);
-      ones_row = -1;
+      ss.xb = ab + (long long)(16 * c) * L;
+      ss.c_count = min(16, n - 16 * c);
+      ss.ones_row = -1;
       shift = (tap - 1) * p.dil;
     } else {
       const int c = k - 3 * CH;
-      xb = ub + (long long)(16 * c) * L;
-      c_count = min(16, h - 16 * c);
-      ones_row = h - 16 * c;                         // in [0, 16) on exactly one conditioning stage
-      shift = 0;
+      ss.xb = ub + (long long)(16 * c) * L;
+      ss.c_count = min(16, h - 16 * c);
+      ss.ones_row = h - 16 * c;                        // in [0, 16) on exactly one conditioning stage
     }
     const int tbase = t0 + shift;
-    const int t4 = tbase & ~3;
-    const bool spill = (tbase & 3) != 0;
-#pragma unroll
-    for (int i = 0; i < (NI1 + 3) / 4; ++i) {
-      const int idx = wave_s + 4 * i;
-      if (idx >= NI1) break;                         // wave-uniform
-      if (idx < NA) {
-        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((WN_EXP & 4) ? zero16 : asrc + idx * 1024 + lane * 16),
-                                         WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
-      } else {
-        const int bi = idx - NA;
-        const int gq = bi >= WN_NBLK ? 1 : 0, m = bi - gq * WN_NBLK;
-        const int row = 8 * gq + (lane >> 3);
-        const int t = t4 + 32 * m + 4 * (lane & 7);
-        bool ok = row < c_count && t >= 0 && t < L;
-        if (m == WN_NBLK - 1) ok = ok && spill && (lane & 7) == 0;
-        if (WN_EXP & 2) ok = false;
-        const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : (row == ones_row ? ones16 : zero16);
-        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_A_BYTES + gq * WN_GS + m * 1024), 16, 0, 0);
-      }
+    ss.t4 = tbase & ~3;
+    ss.spill = (tbase & 3) != 0;
+    return ss;
+  };
+  auto issue_piece = [&](const StageSrc& ss, int i) {
+    if (ss.gemm2) {
+      const int idx = ss.a0 + wave_s + 4 * i;
+      if (i < 4 && idx < NA)
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((WN_EXP & 4) ? zero16 : ss.asrc + idx * 1024 + lane * 16),
+                                         WN_LDS_VOID(ss.sl + idx * 1024), 16, 0, 0);
+      return;
     }
+    const int idx = wave_s + 4 * i;
+    if (idx >= NI1) return;                            // wave-uniform
+    if (idx < NA) {
+      __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((WN_EXP & 4) ? zero16 : ss.asrc + idx * 1024 + lane * 16),
+                                       WN_LDS_VOID(ss.sl + idx * 1024), 16, 0, 0);
+    } else {
+      const int bi = idx - NA;
+      const int gq = bi >= WN_NBLK ? 1 : 0, m = bi - gq * WN_NBLK;
+      const int row = 8 * gq + (lane >> 3);
+      const int t = ss.t4 + 32 * m + 4 * (lane & 7);
+      bool ok = row < ss.c_count && t >= 0 && t < L;
+      if (m == WN_NBLK - 1) ok = ok && ss.spill && (lane & 7) == 0;
+      if (WN_EXP & 2) ok = false;
+      const char* src = ok ? reinterpret_cast<const char*>(ss.xb + ((long long)row * L + t)) : (row == ss.ones_row ? ones16 : zero16);
+      __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(ss.sl + WN_A_BYTES + gq * WN_GS + m * 1024), 16, 0, 0);
+    }
+  };
+  constexpr int NPW1 = (NI1 + 3) / 4;                  // pieces per wave per GEMM-1 stage (waves >= NI1 % 4 issue one fewer)
+  auto issue = [&](int k, int slot) {
+    const StageSrc ss = stage_src(k, slot);
+#pragma unroll
+    for (int i = 0; i < NPW1; ++i) issue_piece(ss, i);
   };
   // wait until this wave's pieces of the stage about to be read have landed; `next` = the one stage issued after it
   auto wait_for = [&](int next, int S) {
@@ -388,7 +404,15 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     __builtin_amdgcn_s_barrier();                      // stage k is in LDS for everyone; the slot refilled next is drained
     WN_T(tc);
     WN_ACC(2, tb, tc);                                 // barrier
-    issue(k + 2, slot >= 1 ? slot - 1 : 2);            // (k + 2 < S always holds here: 8 k-steps of GEMM 2 follow)
+    // stage k+2 goes into the slot every wave has just finished reading (k + 2 < S always holds here: 8 k-steps of
+    // GEMM 2 follow).  Its pieces are issued one by one BETWEEN the MFMA triples below: an LDS-DMA issue costs the wave
+    // 60-180 cycles, an MFMA holds the issue port for 8 of its 32 — interleaved, the address arithmetic and the issue
+    // ride in the matrix pipe's shadow instead of in front of it.
+    const StageSrc nxt = stage_src(k + 2, slot >= 1 ? slot - 1 : 2);
+#if !WN_INTERLEAVE
+#pragma unroll
+    for (int i = 0; i < NPW1; ++i) issue_piece(nxt, i);
+#endif
     WN_T(td);
     WN_ACC(3, tc, td);                                 // LDS-DMA issue
     int shift = 0;
@@ -418,10 +442,19 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     for (int mb = 0; mb < 8; ++mb) {
       const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
       const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
-      if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh), "v"(bl)); continue; }
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+      if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh), "v"(bl)); }
+      else {
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+      }
+#if WN_INTERLEAVE
+      if (mb < NPW1) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(nxt, mb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
     WN_T(tf);
     WN_ACC(5, te, tf);                                 // A fragments + MFMA issue
@@ -488,17 +521,34 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
     const int k = S1 + ks;
     if (ks >= 2) wait_for(k + 1, S);                   // k-steps S1 and S1+1 landed at the drain above
     if (ks >= 1) __builtin_amdgcn_s_barrier();
-    if (k + 2 < S) issue(k + 2, slot >= 1 ? slot - 1 : 2);
+    const bool more = k + 2 < S;
+    const StageSrc nxt = stage_src(more ? k + 2 : k, slot >= 1 ? slot - 1 : 2);
+#if !WN_INTERLEAVE
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) issue_piece(nxt, i);
+    }
+#endif
     const char* base = ldsb + slot * WN_SLOT;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
-      if (p.last && mb < 4) continue;                  // wave-uniform
-      const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
-      const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
-      if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh2[ks]), "v"(bl2[ks])); continue; }
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh2[ks], acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2[ks], acc[mb], 0, 0, 0);
-      acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh2[ks], acc[mb], 0, 0, 0);
+      if (!(p.last && mb < 4)) {                       // wave-uniform
+        const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
+        const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+        if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh2[ks]), "v"(bl2[ks])); }
+        else {
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh2[ks], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl2[ks], acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh2[ks], acc[mb], 0, 0, 0);
+        }
+      }
+#if WN_INTERLEAVE
+      if (more && mb >= 4) {                           // four pieces per wave, behind the skip-row blocks (live on every layer)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(nxt, mb - 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
     slot = slot == 2 ? 0 : slot + 1;
   }
@@ -757,6 +807,234 @@ extern "C" int fst_wn_layer_bwd(const float* d_a, const float* d_out, const floa
   p.n_wg = B * p.tiles_per_seq;
   if (int rc = fst_allow_full_lds((const void*)wn_layer_bwd_kernel, "fst_wn_layer_bwd")) return rc;
   hipLaunchKernelGGL(wn_layer_bwd_kernel, dim3((unsigned)p.n_wg), dim3(256), WN_BW_LDS, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// data gradient of the in_layer + cond_layer:   d_a = d_a_next + W_inᵀ (*) dg  (3 dilated taps),   d_u0 += W_condᵀ · dg
+//
+// The LDS-DMA path, not the matrix pipe, bounds these GEMMs (tools/dma_ring_probe.hip: ≈34 GB/s per CU, 8.7 TB/s chip-wide,
+// whatever the prefetch depth): so the kernel is shaped to move few bytes per MFMA.
+//   * one stage = 16 channels of dg with ALL THREE taps: the B window [16 ch][256 + 2·dil (+3)] is fetched once and each tap
+//     reads it at its own column offset (a third of the B bytes for small dilations; the per-tap form fetched three windows);
+//   * the 25 conditioning rows ride along as a fifth row block of the centre tap instead of a second pass over dg;
+//   * a workgroup = 8 waves = one batch element × 256 time samples (each wave 32 samples × 5 row blocks): the weight bytes
+//     per output sample are half those of a 128-sample tile.
+// Image: per 16-channel chunk 13 row blocks × (1 KiB hi + 1 KiB lo): [tap 0: 4 blocks of d_a rows][tap 1: 4 + the d_u0 block]
+// [tap 2: 4]; tap τ multiplies dg at t + (1 − τ)·dil.  Ring of 3 slots (2 when the window of a large dilation needs the room).
+// ------------------------------------------------------------------------------------------------
+#define DG_TN 256
+#define DG_A_BLOCKS 13
+#define DG_A_BYTES (DG_A_BLOCKS * 2048)
+
+struct WnPackDgradParams {
+  const float* in_w;    // [2n][n][3]
+  const float* cond_w;  // [2n][h]
+  int n, h, CHK;
+  uint4* img;
+};
+
+__global__ __launch_bounds__(64) void wn_pack_dgrad_kernel(WnPackDgradParams p) {
+  const int lane = threadIdx.x, ab = blockIdx.x % DG_A_BLOCKS, c = blockIdx.x / DG_A_BLOCKS;
+  const int n = p.n, h = p.h, hh = lane >> 5, l31 = lane & 31;
+  // block ab of the chunk -> (tap, row block)
+  int tap, blk;
+  if (ab < 4) { tap = 0; blk = ab; } else if (ab < 9) { tap = 1; blk = ab - 4; } else { tap = 2; blk = ab - 9; }
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * c + 8 * hh + j;                   // dg channel = output row of the forward convs
+    float w = 0.f;
+    if (k < 2 * n) {
+      if (blk < 4) {
+        const int m = blk * 32 + l31;
+        if (m < n) w = p.in_w[((long long)k * n + m) * 3 + tap];
+      } else {
+        if (l31 < h) w = p.cond_w[(long long)k * h + l31];
+      }
+    }
+    v[j] = w;
+  }
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wn_split_pair(v[2 * j], v[2 * j + 1], hi[j], lo[j]);
+  uint4* dst = p.img + (long long)blockIdx.x * 128 + lane;
+  dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  dst[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  if (blockIdx.x == 0 && lane == 0) p.img[(long long)gridDim.x * 128] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+extern "C" int64_t fst_wn_dgrad_image_bytes(int n) {
+  if (n <= 0) return -1;
+  return (int64_t)((2 * n + 15) / 16) * DG_A_BYTES + 16;
+}
+
+extern "C" int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, void* image, int64_t image_bytes,
+                                 void* stream) {
+  FST_REQUIRE(in_w && cond_w && image && n > 0 && n <= 128 && h > 0 && h <= 32, "fst_wn_pack_dgrad: needs n <= 128, h <= 32 (n=%d h=%d)", n, h);
+  FST_REQUIRE(image_bytes == fst_wn_dgrad_image_bytes(n), "fst_wn_pack_dgrad: image is %lld bytes, expected %lld",
+              (long long)image_bytes, (long long)fst_wn_dgrad_image_bytes(n));
+  FST_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, "fst_wn_pack_dgrad: image must be 16-byte aligned");
+  WnPackDgradParams p = {in_w, cond_w, n, h, (2 * n + 15) / 16, static_cast<uint4*>(image)};
+  hipLaunchKernelGGL(wn_pack_dgrad_kernel, dim3((unsigned)(p.CHK * DG_A_BLOCKS)), dim3(64), 0, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+struct WnDgradParams {
+  const float* dg;      // [B][2n][L]
+  const char* img;
+  const float* d_a;     // [B][n][L] residual cotangent, or null
+  float* d_a_new;       // [B][n][L]
+  float* d_u0;          // [B][h][L], accumulated
+  int B, L, n, h, dil, CHK, tiles_per_seq, n_wg;
+  int nblkw;            // 32-sample column blocks of the window
+  int gsw;              // bytes per 8-channel row group of the window
+  int slot;             // bytes per ring slot
+  int ns;               // ring slots (3, or 2 for wide windows)
+};
+
+template <int N>
+__device__ __forceinline__ void wn_wait_sw(int n) {
+  // counted wait for a wave-uniform run-time count (the immediates are instantiated below)
+  if (n == N) { wn_wait_vmcnt<N>(); return; }
+  if constexpr (N > 0) wn_wait_sw<N - 1>(n);
+}
+
+__global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wg = blockIdx.x;
+  if ((p.n_wg & 7) == 0) wg = (wg & 7) * (p.n_wg >> 3) + (wg >> 3);
+  const int b = wg / p.tiles_per_seq;
+  const int t0 = (wg - b * p.tiles_per_seq) * DG_TN;
+  const int wave_n0 = wave_s * 32;
+  const int L = p.L, n = p.n, CHK = p.CHK, dil = p.dil;
+  const char* const zero16 = p.img + (long long)CHK * DG_A_BYTES;
+  const float* const dgb = p.dg + (long long)b * (2 * n) * L;
+  const int w_lo = t0 - dil;                           // first column any tap needs
+  const int w4 = w_lo & ~3, sub = w_lo & 3;
+  const int NI = DG_A_BLOCKS * 2 + 2 * p.nblkw;        // 1-KiB pieces per stage
+  const int my_pieces = (NI - wave_s + 7) >> 3;        // pieces idx = wave + 8 i < NI
+  const int depth = p.ns - 1;                          // stages in flight
+
+  auto issue = [&](int c, int slot) {
+    char* const sl = ldsb + slot * p.slot;
+    const char* asrc = p.img + (long long)c * DG_A_BYTES;
+    const float* xb = dgb + (long long)(16 * c) * L;
+    const int c_count = min(16, 2 * n - 16 * c);
+    for (int idx = wave_s; idx < NI; idx += 8) {         // wave-uniform trip count
+      if (idx < 2 * DG_A_BLOCKS) {
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+      } else {
+        const int bi = idx - 2 * DG_A_BLOCKS;
+        const int gq = bi >= p.nblkw ? 1 : 0, m = bi - gq * p.nblkw;
+        const int row = 8 * gq + (lane >> 3);
+        const int t = w4 + 32 * m + 4 * (lane & 7);
+        const bool ok = row < c_count && t >= 0 && t < L;
+        const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + DG_A_BYTES + gq * p.gsw + m * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[5];
+#pragma unroll
+  for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+  for (int d = 0; d < depth && d < CHK; ++d) issue(d, d);
+  int slot = 0;
+  for (int c = 0; c < CHK; ++c) {
+    // stages still allowed in flight behind stage c: those already issued, i.e. min(depth - 1, CHK - 1 - c)
+    const int newer = min(depth - 1, CHK - 1 - c);
+    wn_wait_sw<16>(newer * my_pieces);
+    __builtin_amdgcn_s_barrier();
+    if (c + depth < CHK) issue(c + depth, (slot + depth) % p.ns);
+    const char* base = ldsb + slot * p.slot;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      const int colx = wave_n0 + l31 + (2 - tap) * dil + sub;
+      const char* bp = base + DG_A_BYTES + half * p.gsw + (colx >> 5) * 1024 + (colx & 31) * 4;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
+      wn_u32x4 bh4, bl4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned hh, ll;
+        wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
+        bh4[j] = hh; bl4[j] = ll;
+      }
+      const wn_bf16x8 bh = __builtin_bit_cast(wn_bf16x8, bh4), bl = __builtin_bit_cast(wn_bf16x8, bl4);
+      const char* ab = base + (tap == 0 ? 0 : (tap == 1 ? 4 : 9)) * 2048;
+#pragma unroll
+      for (int mb = 0; mb < 5; ++mb) {
+        if (mb == 4 && tap != 1) continue;               // the d_u0 block exists on the centre tap only
+        const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + lane * 16);
+        const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + 1024 + lane * 16);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+      }
+    }
+    slot = slot + 1 == p.ns ? 0 : slot + 1;
+  }
+  __syncthreads();                                     // every wave is past its last fragment read: the ring becomes tiles
+  float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
+  const int tcol = t0 + wave_n0;
+  // five tiles: d_a rows of block i (operand: the incoming d_a, if any), then the d_u0 rows (operand: d_u0 itself)
+  auto e_src = [&](int i) -> const float* {
+    return i < 4 ? (p.d_a ? p.d_a + ((long long)b * n + i * 32) * L : nullptr) : p.d_u0 + (long long)b * p.h * L;
+  };
+  auto e_rows = [&](int i) -> int { return i < 4 ? (p.d_a ? n - i * 32 : 0) : p.h; };
+  float4 eq[2][4];
+  wn_fetch_tile(eq[0], e_src(0), e_rows(0), L, tcol, lane);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    if (i + 1 < 5) wn_fetch_tile(eq[(i + 1) & 1], e_src(i + 1), e_rows(i + 1), L, tcol, lane);
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[i][r];
+    float* dst = i < 4 ? p.d_a_new + ((long long)b * n + i * 32) * L : p.d_u0 + (long long)b * p.h * L;
+    wn_store_tile_add(v, eq[i & 1], tile, dst, i < 4 ? n - i * 32 : p.h, L, tcol, lane);
+  }
+}
+
+extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new,
+                                  float* d_u0, int B, int L, int n, int h, int dil, int64_t numel_a, int64_t numel_u0,
+                                  void* stream) {
+  FST_REQUIRE(dg && image && d_a_new && d_u0, "fst_wn_layer_dgrad: null operand");
+  FST_REQUIRE(B > 0 && L > 0 && n > 0 && n <= 128 && h > 0 && h <= 32 && dil > 0, "fst_wn_layer_dgrad: B=%d L=%d n=%d h=%d dil=%d", B, L,
+              n, h, dil);
+  FST_REQUIRE((long long)B * n * L == (long long)numel_a && (long long)B * h * L == (long long)numel_u0,
+              "fst_wn_layer_dgrad: B*n*L / B*h*L do not match the element counts %lld / %lld", (long long)numel_a, (long long)numel_u0);
+  FST_REQUIRE(image_bytes == fst_wn_dgrad_image_bytes(n), "fst_wn_layer_dgrad: image is %lld bytes, expected %lld",
+              (long long)image_bytes, (long long)fst_wn_dgrad_image_bytes(n));
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  FST_REQUIRE(L % 4 == 0 && al16(dg) && al16(image) && al16(d_a) && al16(d_a_new) && al16(d_u0),
+              "fst_wn_layer_dgrad: needs L %% 4 == 0 and 16-byte aligned tensors (L=%d)", L);
+  WnDgradParams p;
+  p.dg = dg; p.img = static_cast<const char*>(image); p.d_a = d_a; p.d_a_new = d_a_new; p.d_u0 = d_u0;
+  p.B = B; p.L = L; p.n = n; p.h = h; p.dil = dil; p.CHK = (2 * n + 15) / 16;
+  p.tiles_per_seq = (L + DG_TN - 1) / DG_TN;
+  p.n_wg = B * p.tiles_per_seq;
+  p.nblkw = (DG_TN + 2 * dil + 3 + 31) / 32;
+  p.gsw = p.nblkw * 1024 + 128;
+  p.slot = DG_A_BYTES + 2 * p.gsw;
+  p.ns = 3 * p.slot <= 160 * 1024 ? 3 : 2;
+  FST_REQUIRE(2 * p.slot <= 160 * 1024, "fst_wn_layer_dgrad: dilation %d needs a %d-byte window slot: too large for LDS", dil, p.slot);
+  const int NI = DG_A_BLOCKS * 2 + 2 * p.nblkw;
+  FST_REQUIRE(((NI + 7) / 8) * (p.ns - 1) <= 16, "fst_wn_layer_dgrad: %d pieces per stage exceed the counted-wait table", NI);
+  size_t lds_bytes = (size_t)p.ns * p.slot;
+  if (lds_bytes < 8 * WN_TILE_BYTES) lds_bytes = 8 * WN_TILE_BYTES;
+  if (int rc = fst_allow_full_lds((const void*)wn_layer_dgrad_kernel, "fst_wn_layer_dgrad")) return rc;
+  hipLaunchKernelGGL(wn_layer_dgrad_kernel, dim3((unsigned)p.n_wg), dim3(512), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }

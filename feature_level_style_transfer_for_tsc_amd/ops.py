@@ -735,6 +735,40 @@ def wn_layer_bwd(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, img: Tensor, 
         KERNEL_TIMER.end("wn_layer_bwd_kernel", t0, 2.0 * B * L * n * k, 4.0 * B * L * (k + 4 * n))
 
 
+def wn_pack_dgrad(in_w: Tensor, cond_w: Tensor, n: int, h: int) -> Tensor:
+    lib = _lib.load()
+    key = None
+    if _PACK_CACHE is not None:
+        key = ("wn_dgrad", n, h, in_w.data_ptr(), in_w._version, cond_w.data_ptr(), cond_w._version)
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            return hit[0]
+    nbytes = lib.fst_wn_dgrad_image_bytes(n)
+    img = torch.empty(nbytes // 4, device=in_w.device, dtype=torch.float32)
+    src = (in_w.contiguous(), cond_w.contiguous())
+    check(lib.fst_wn_pack_dgrad(ptr(src[0]), ptr(src[1]), n, h, ptr(img), nbytes, stream_ptr()), "fst_wn_pack_dgrad")
+    if key is not None:
+        _PACK_CACHE[key] = (img, in_w, cond_w, src)
+    return img
+
+
+def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor, n: int, h: int, dil: int) -> Tensor:
+    """returns d_a_new = d_a + W_inᵀ (*) dg;  d_u0 += W_condᵀ·dg  — one launch (csrc/wn_fused.hip)."""
+    lib = _lib.load()
+    B, _, L = dg.shape
+    d_a_new = torch.empty(B, n, L, device=dg.device, dtype=torch.float32)
+    numel = _same_numel(d_a_new, d_a)
+    if dg.numel() != 2 * numel or not dg.is_contiguous() or not d_u0.is_contiguous():
+        raise ValueError("wn_layer_dgrad: dg must be contiguous [B, 2n, L], d_u0 contiguous [B, h, L]")
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_wn_layer_dgrad(ptr(dg), ptr(img), img.numel() * 4, ptr(d_a), ptr(d_a_new), ptr(d_u0), B, L, n, h, dil, numel,
+                                 d_u0.numel(), stream_ptr()), "fst_wn_layer_dgrad")
+    if t0 is not None:
+        KERNEL_TIMER.end("wn_layer_dgrad_kernel", t0, 2.0 * B * L * 2 * n * (3 * n + h),
+                         4.0 * B * L * (2 * n + (n if d_a is not None else 0) + n + 2 * h))
+    return d_a_new
+
+
 class WNFn(torch.autograd.Function):
     """The whole gated dilated-conv stack (:101-123) as one autograd node.
 
@@ -866,7 +900,10 @@ class WNFn(torch.autograd.Function):
                 d_in_b[i] = row_sum(dg)
                 d_cond_b[i] = d_in_b[i]
             # ---- into the layer input (residual path + dilated conv) and into the conditioning input
-            d_a = S.ins[i].grad_x01(dg, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], d_a, d_u0)
+            if ctx.fused and h <= 32 and os.environ.get("FST_WN_DGRAD", "fused") == "fused":
+                d_a = wn_layer_dgrad(dg, wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h), d_a, d_u0, n, h, 2 ** i)
+            else:
+                d_a = S.ins[i].grad_x01(dg, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], d_a, d_u0)
         S.start.grad_x0(d_a, start_w, out=d_u0, flags=EPI_ACC1)
         d_start_w = d_start_b = None
         if need_w:

@@ -203,6 +203,16 @@ int fst_wn_pack_bwd(const float* rs_w, int n, int last, void* image, int64_t ima
 int fst_wn_layer_bwd(const float* d_a_next /* NULL iff last */, const float* d_out, const float* ts, const void* image,
                      int64_t image_bytes, float* dg, int last, int B, int L, int n, int64_t numel_a, void* stream);
 
+/* Data gradient of the same layer's in_layer + cond_layer in ONE launch (the transposed dilated conv and the transposed
+ * 1x1 autograd derives for Simplified_NF_WaveGlow.py:107-112):
+ *   d_a_new = d_a + Σ_τ W_in[:, :, τ]ᵀ · dg[t + (1 − τ)·dil]      (d_a NULL: no residual cotangent — the last layer)
+ *   d_u0   += W_condᵀ · dg
+ * in_w [2n][n][3], cond_w [2n][h] (this layer's rows); dg [B][2n][L]; d_a / d_a_new [B][n][L]; d_u0 [B][h][L] contiguous. */
+int64_t fst_wn_dgrad_image_bytes(int n);
+int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, void* image, int64_t image_bytes, void* stream);
+int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new, float* d_u0,
+                       int B, int L, int n, int h, int dil, int64_t numel_a, int64_t numel_u0, void* stream);
+
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */
 int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,

@@ -486,3 +486,25 @@ def test_gru_recurrence_matches_torch_gru(B, S, C, t_last, dev_index):
                             (b_hh, gru.bias_hh_l0, "db_hh")):
         assert_close(got.grad, want.grad, 5e-5, name)
     assert float(xd.grad[:, t_last + 1:].abs().max()) == 0.0 if t_last + 1 < S else True      # steps beyond t_last: no gradient
+
+
+@pytest.mark.parametrize("n,h,B,L,dil,res", [(120, 25, 2, 512, 1, True), (120, 25, 2, 512, 2, True), (120, 25, 3, 512, 16, True),
+                                             (120, 25, 2, 512, 128, False), (120, 25, 2, 1024, 64, True), (120, 25, 2, 200, 4, True),
+                                             (8, 3, 3, 40, 2, True), (128, 32, 1, 256, 32, False), (33, 31, 2, 132, 8, True)])
+def test_fused_wn_layer_data_gradient(n, h, B, L, dil, res):
+    """fst_wn_layer_dgrad (transposed dilated 3-tap conv with one tap-merged window per 16 channels + the transposed
+    conditioning 1x1 as a fifth row block) against autograd of the fp64 forward convs."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(n + L + dil)
+    rnd = lambda *s, k=1.0: torch.randn(*s, generator=g, dtype=torch.float64) * k
+    in_w, cond_w = rnd(2 * n, n, 3, k=(3 * n) ** -0.5), rnd(2 * n, h, 1, k=h ** -0.5)
+    a, u0 = rnd(B, n, L).requires_grad_(True), rnd(B, h, L).requires_grad_(True)
+    gg = F.conv1d(a, in_w, None, dilation=dil, padding=dil) + F.conv1d(u0, cond_w)
+    dg = rnd(B, 2 * n, L)
+    da_ref, du_ref = torch.autograd.grad(gg, (a, u0), dg)
+    d_a_in, d_u0_in = (rnd(B, n, L) if res else None), rnd(B, h, L)
+    f = lambda x: None if x is None else x.float().to(DEV).contiguous()
+    d_u0 = f(d_u0_in)
+    got = ops.wn_layer_dgrad(f(dg), ops.wn_pack_dgrad(f(in_w), f(cond_w), n, h), f(d_a_in), d_u0, n, h, dil)
+    assert_close(got, da_ref + (d_a_in if res else 0), 2e-5, "d_a")
+    assert_close(d_u0, du_ref + d_u0_in, 2e-5, "d_u0")
