@@ -35,7 +35,7 @@ _SIGNATURES = {
     "fst_pack_weights": (c_int, [_I32P, _I32P, c_int, POINTER(WSrc), POINTER(WSrc), c_int, c_int, c_int, c_int, _P, c_void_p]),
     "fst_pack_weights_bf16x3": (c_int, [_I32P, _I32P, c_int, POINTER(WSrc), POINTER(WSrc), c_int, c_int, c_int, c_int, _P, c_void_p]),
     "fst_unpack_weights": (c_int, [_I32P, _I32P, c_int, _P, c_int, _P, c_int64, c_int64, c_int64, c_int64,
-                                   _P, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+                                   _P, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "fst_mask_taps": (c_int, [_P, _I32P, _I32P, c_int, c_int, c_int, c_void_p]),
     "fst_conv_gemm": (c_int, [_P, c_int64, _P, c_int64, _P, _I32P, _I32P, c_int, _P, _P, c_int64, _P, c_int64,
                               _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

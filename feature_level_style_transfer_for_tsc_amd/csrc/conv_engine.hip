@@ -1185,9 +1185,15 @@ struct WgradParams {
   const int32_t* plan;
   int B, L, M, ksplit, tiles_per_seq, ldw, region_floats, n_regions;
   long long x0_mul_off;   // != 0: the x operand is x0[i]·x0[i + x0_mul_off] (acts = t·s read from the saved gate halves)
+  long long slab_floats;  // != 0: K slice s stores its partial sums plainly into da + s·slab_floats (summed by the unpack)
 };
 
 #define WG_ITEMS 4   // row-blocks (32 packed K-rows each) per workgroup
+// Diagnostic builds only (tools/build_wg_exp.sh): WG_EXP removes one cost at a time from the split-bf16 weight-gradient
+// kernel (wrong results, timing only): 1 no atomics, 2 no MFMAs, 4 no dy fetch, 8 no x fetch, 16 no LDS commit.
+#ifndef WG_EXP
+#define WG_EXP 0
+#endif
 
 // CB: output-channel blocks per wave (M tile = 4*CB*32).  WIDE=false: every chunk is a single tap of ≤ 32
 // channels (window = TW columns, up to WG_ITEMS windows per workgroup); WIDE=true: one windowed chunk of
@@ -1464,12 +1470,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
     }
   };
 
-  if (tile_begin < tile_end) fetch(tile_begin);
+  if (tile_begin < tile_end && !(WG_EXP & 12)) fetch(tile_begin);
   for (int tile = tile_begin; tile < tile_end; ++tile) {
     __syncthreads();   // previous tile's readers are done
-    commit();
+    if (!(WG_EXP & 16)) commit();
     __syncthreads();
-    if (tile + 1 < tile_end) fetch(tile + 1);
+    if (tile + 1 < tile_end && !(WG_EXP & 12)) fetch(tile + 1);
 
     if (BF3) {
       // wave w multiplies item w: rows = its 32 packed K-rows (lane's row: rowoff_w), columns = every output block
@@ -1498,6 +1504,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
             const int blk = i * CB + cb;
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(dyh + blk * 32 * DYB + boff);
             const bf16x8 bl = *reinterpret_cast<const bf16x8*>(dyl + blk * 32 * DYB + boff);
+            if (WG_EXP & 2) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh), "v"(bl)); continue; }
             acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][cb], 0, 0, 0);
             acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][cb], 0, 0, 0);
             acc[i][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][cb], 0, 0, 0);
@@ -1541,8 +1548,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
 #pragma unroll
       for (int i = 0; i < WG_ITEMS; ++i)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-          atomicAdd(p.da + (rec * MBW + i * CB + cb) * 64 + (c & 1) * 32 + l31, acc[i][cb][r]);
+        for (int cb = 0; cb < CB; ++cb) {
+          if (WG_EXP & 1) { if (acc[i][cb][r] == 12345.678f) p.da[0] = 1.f; continue; }
+          float* dst = p.da + (long long)blockIdx.x * p.slab_floats + (rec * MBW + i * CB + cb) * 64 + (c & 1) * 32 + l31;
+          if (p.slab_floats) *dst = acc[i][cb][r]; else atomicAdd(dst, acc[i][cb][r]);
+        }
     }
     return;
   }
@@ -1563,8 +1573,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         const int mbw = wave * CB + cb;
-        float* dst = p.da + (rec * MBW + mbw) * 64 + (c & 1) * 32 + l31;
-        atomicAdd(dst, acc[i][cb][r]);
+        float* dst = p.da + (long long)blockIdx.x * p.slab_floats + (rec * MBW + mbw) * 64 + (c & 1) * 32 + l31;
+        if (p.slab_floats) *dst = acc[i][cb][r]; else atomicAdd(dst, acc[i][cb][r]);
       }
     }
   }
@@ -1608,6 +1618,7 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
   p.dy = dy; p.dy_bs = dy_bs; p.dy2 = dy2; p.dy2_bs = dy2_bs; p.msplit = msplit;
   p.da = da_packed; p.plan = plan_dev; p.B = B; p.L = L; p.M = M;
   p.x0_mul_off = x0_mul_off;
+  p.slab_floats = (flags & FST_WGRAD_SLABS) ? (long long)pv.total_records * pv.MB * 64 : 0;
   p.tiles_per_seq = (L + TW - 1) / TW;
   const int n_tiles = B * p.tiles_per_seq;
   p.ksplit = ksplit < n_tiles ? ksplit : n_tiles;
@@ -1697,6 +1708,8 @@ struct PackParams {
   int M;               // rows [row_base, M) are valid; the weight view is indexed with m - row_base
   int unpack;
   int g_begin, g_end, row_base;
+  int n_slabs;         // unpack: number of partial-sum slabs to add (1 = a plain packed gradient)
+  long long slab_floats;
 };
 
 __global__ __launch_bounds__(256) void pack_kernel(PackParams p, const int32_t* __restrict__ plan) {
@@ -1723,7 +1736,11 @@ __global__ __launch_bounds__(256) void pack_kernel(PackParams p, const int32_t* 
                            (long long)(lo + tapi) * p.src[s].st;
     float* ap = p.a + ((long long)e[2] + rec) * (MB * 64) + mb * 64 + lane;
     if (p.unpack) {
-      if (valid) p.dst[s][woff] = *ap;
+      if (valid) {
+        float v = *ap;
+        for (int sl = 1; sl < p.n_slabs; ++sl) v += ap[(long long)sl * p.slab_floats];
+        p.dst[s][woff] = v;
+      }
     } else {
       *ap = valid ? p.src[s].w[woff] : 0.f;
     }
@@ -1836,9 +1853,11 @@ extern "C" int fst_pack_weights_bf16x3(const int32_t* plan_dev, const int32_t* p
 
 extern "C" int fst_unpack_weights(const int32_t* plan_dev, const int32_t* plan_host, int plan_len, const float* a_packed,
                                   int M, float* dw0, int64_t off0_0, int64_t sm0, int64_t sc0, int64_t st0, float* dw1,
-                                  int64_t off0_1, int64_t sm1, int64_t sc1, int64_t st1, void* stream) {
-  FST_REQUIRE(plan_dev && dw0 && a_packed, "fst_unpack_weights: null operand");
+                                  int64_t off0_1, int64_t sm1, int64_t sc1, int64_t st1, int n_slabs, void* stream) {
+  FST_REQUIRE(plan_dev && dw0 && a_packed && n_slabs >= 1, "fst_unpack_weights: null operand / n_slabs=%d", n_slabs);
   PackParams p = {};
+  p.n_slabs = n_slabs;
+  p.slab_floats = (plan_host && plan_len >= FST_PLAN_HDR) ? (long long)plan_host[7] * plan_host[2] * 64 : 0;
   p.src[0] = {nullptr, off0_0, sm0, sc0, st0};
   p.src[1] = {nullptr, off0_1, sm1, sc1, st1};
   p.dst[0] = dw0; p.dst[1] = dw1;

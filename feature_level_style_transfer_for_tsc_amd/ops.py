@@ -18,6 +18,9 @@ from .plan import Plan, Segment, build_plan, pick_mb
 
 EPI_RELU, EPI_ACC2, EPI_ATOMIC, EPI_ACC1 = 1, 2, 4, 8
 GEMM_BF16X3 = 16
+WGRAD_SLABS = 32
+# weight gradients: one partial-sum slab per K slice, added by the unpack pass (default) instead of fp32 atomics into one buffer
+WGRAD_TWO_STAGE = os.environ.get("FST_WGRAD_ATOMICS", "0") != "1"
 # Arithmetic of the pipelined forward / data-gradient GEMMs: "bf16x3" = split-bf16 operands on the bf16 matrix cores
 # (hi*hi + hi*lo + lo*hi, fp32 accumulate, ~5e-6 of the output scale); "f32" = exact f32 MFMA everywhere.
 MATH = os.environ.get("FST_MATH", "bf16x3")
@@ -200,9 +203,11 @@ def _pack_weights(plan: Plan, M: int, w0: Tensor, s0, w1: Optional[Tensor], s1, 
 
 
 def unpack_weights(plan: Plan, M: int, a: Tensor, dw0: Tensor, s0, dw1: Optional[Tensor] = None, s1=(0, 0, 0, 0)) -> None:
+    """``a``: a packed gradient, or [n_slabs, packed_floats] partial sums that are added on the way out."""
     lib = _lib.load()
+    n_slabs = a.size(0) if a.dim() == 2 else 1
     check(lib.fst_unpack_weights(ptr(plan.dev(a.device)), plan.host_ptr(), plan.length, ptr(a), M, ptr(dw0), *s0,
-                                 ptr(dw1), *s1, stream_ptr()), "fst_unpack_weights")
+                                 ptr(dw1), *s1, n_slabs, stream_ptr()), "fst_unpack_weights")
 
 
 def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Optional[Tensor], B: int, L: int, M: int,
@@ -244,7 +249,11 @@ def conv_gemm(plan: Plan, a: Tensor, x0: Tensor, x1: Optional[Tensor], bias: Opt
 def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor], msplit: int, B: int,
                L: int, M: int, ksplit: int, x0_mul_off: int = 0) -> Tensor:
     lib = _lib.load()
-    da = torch.zeros(plan.packed_floats, device=x0.device, dtype=torch.float32)
+    if WGRAD_TWO_STAGE:
+        n_slabs = max(1, min(ksplit, B * ((L + 31) // 32)))                    # the library clamps the K split the same way
+        da = torch.empty(n_slabs, plan.packed_floats, device=x0.device, dtype=torch.float32)
+    else:
+        da = torch.zeros(plan.packed_floats, device=x0.device, dtype=torch.float32)
     x0_bs, _ = _ncl(x0, "x0")
     x1_bs = _ncl(x1, "x1")[0] if x1 is not None else 0
     dy_bs, _ = _ncl(dy, "dy")
@@ -253,7 +262,8 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
     bf3 = MATH == "bf16x3"
     check(lib.fst_conv_wgrad(ptr(x0), x0_bs, ptr(x1), x1_bs, ptr(dy), dy_bs, ptr(dy2), dy2_bs, msplit, ptr(da),
                              ptr(plan.dev(x0.device)), plan.host_ptr(), plan.length, B, L, M, ksplit,
-                             GEMM_BF16X3 if bf3 else 0, x0_mul_off, stream_ptr()), "fst_conv_wgrad")
+                             (GEMM_BF16X3 if bf3 else 0) | (WGRAD_SLABS if WGRAD_TWO_STAGE else 0), x0_mul_off, stream_ptr()),
+          "fst_conv_wgrad")
     if t0 is not None:
         wide = bool(((plan.entries()[:, :, 1] - plan.entries()[:, :, 0]) > 1).any())
         if wide:

@@ -80,6 +80,7 @@ int fst_unpack_weights(const int32_t* plan_dev, const int32_t* plan_host, int pl
                        const float* a_packed, int M,
                        float* dw0, int64_t off0_0, int64_t sm0, int64_t sc0, int64_t st0,
                        float* dw1, int64_t off0_1, int64_t sm1, int64_t sc1, int64_t st1,
+                       int n_slabs /* a_packed = n_slabs partial sums of plan.packed_floats each, added here */,
                        void* stream);
 
 /* Omni-scale re-masking W ← W ⊙ mask, mask given as per-output-channel live tap range.
@@ -101,6 +102,7 @@ int fst_mask_taps(float* w, const int32_t* live_lo, const int32_t* live_hi, int 
 #define FST_EPI_ATOMIC  4
 #define FST_EPI_ACC1    8
 #define FST_GEMM_BF16X3 16
+#define FST_WGRAD_SLABS 32   /* fst_conv_wgrad: da_packed holds one partial-sum slab per K slice (no atomics, no zero fill) */
 int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs,
                   const float* a_packed, const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
                   const float* bias,
@@ -114,6 +116,9 @@ int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_bs
  * masked-tap gradients the reference's GradNorm consumes, train_and_test.py:685-690).
  * FST_GEMM_BF16X3: products on v_mfma_f32_32x32x16_bf16 with both operands split into two bf16 parts
  * (hi*hi + hi*lo + lo*hi, fp32 accumulate), same layout of da_packed.
+ * FST_WGRAD_SLABS: instead of fp32 atomics into one zero-filled buffer (1.3 TB/s chip-wide: 50 MB of them per in_layer
+ * launch), K slice s stores its partial sums plainly into da_packed + s·packed_floats (the buffer holds
+ * min(ksplit, B·⌈L/32⌉) slabs, no zero fill); fst_unpack_weights(n_slabs) adds them.
  * x0_mul_off != 0 (single-input 1x1 plans only): the x operand is the elementwise product x0[i]·x0[i + x0_mul_off] formed
  * while staging — the res_skip weight gradient reads acts = t·s from the gate halves the fused forward saved
  * (x0 = the t rows of ts, offset n·L to the s rows), so acts itself is never written to HBM. */
