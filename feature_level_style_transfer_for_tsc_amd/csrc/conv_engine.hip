@@ -1737,8 +1737,16 @@ __global__ __launch_bounds__(256) void pack_kernel(PackParams p, const int32_t* 
     float* ap = p.a + ((long long)e[2] + rec) * (MB * 64) + mb * 64 + lane;
     if (p.unpack) {
       if (valid) {
-        float v = *ap;
-        for (int sl = 1; sl < p.n_slabs; ++sl) v += ap[(long long)sl * p.slab_floats];
+        // partial-sum slabs: eight independent loads in flight per thread (a serial chain of n_slabs loads is latency-bound)
+        float v = 0.f;
+        int sl = 0;
+        for (; sl + 8 <= p.n_slabs; sl += 8) {
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t[j] = ap[(long long)(sl + j) * p.slab_floats];
+          v += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        for (; sl < p.n_slabs; ++sl) v += ap[(long long)sl * p.slab_floats];
         p.dst[s][woff] = v;
       }
     } else {
