@@ -60,10 +60,11 @@ _SIGNATURES = {
                                  c_int, c_int64, c_void_p]),
     "fst_wn_bwd_image_bytes": (c_int64, [c_int, c_int]),
     "fst_wn_pack_bwd": (c_int, [_P, c_int, c_int, _P, c_int64, c_void_p]),
-    "fst_wn_layer_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_wn_layer_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_dgrad_image_bytes": (c_int64, [c_int]),
     "fst_wn_pack_dgrad": (c_int, [_P, _P, c_int, c_int, _P, c_int64, c_void_p]),
-    "fst_wn_layer_dgrad": (c_int, [_P, _P, c_int64, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "fst_wn_layer_dgrad": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
+                                   c_void_p]),
     "fst_gru_fwd": (c_int, [_P, _P, _P, _P, _P, _I32P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_gru_bwd": (c_int, [_P, _P, _P, _P, _I32P, c_int, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_axpy": (c_int, [_P, _P, c_float, c_int64, c_void_p]),

@@ -283,6 +283,23 @@ __device__ __forceinline__ void wn_store_tile_add(const float (&v)[16], const fl
   }
 }
 
+// Row sums of an accumulator tile on its way out (bias gradients: Σ_{b,t} of every row): after the transpose each lane
+// holds four consecutive samples of rows rrow + 8j, so a row's 32 samples are 8 lanes × float4 — three butterfly steps,
+// then one LDS float add per row and wave.  `rows` = LDS array indexed by the tile's absolute row.
+__device__ __forceinline__ void wn_tile_row_sums(const float* tile, float* rows, int row0, int rows_valid, int L, int t, int lane) {
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  const bool t_ok = t + c4 < L;                          // samples beyond the sequence are not part of the sum (L % 4 == 0)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 o = *reinterpret_cast<const float4*>(tile + (rrow + 8 * j) * 36 + c4);
+    float s4 = t_ok ? (o.x + o.y) + (o.z + o.w) : 0.f;
+    s4 += __shfl_xor(s4, 1, 64);
+    s4 += __shfl_xor(s4, 2, 64);
+    s4 += __shfl_xor(s4, 4, 64);
+    if ((lane & 7) == 0 && rrow + 8 * j < rows_valid) atomicAdd(rows + row0 + rrow + 8 * j, s4);
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NA = WN_A_BYTES / 1024;              // 16 one-KiB pieces of A per stage
@@ -676,6 +693,7 @@ struct WnBwdParams {
   const float* ts;     // [B][2n][L]
   const char* img;
   float* dg;           // [B][2n][L]
+  float* row_sums;     // optional [n_wg][256]: per-workgroup Σ_t dg[row] (rows [0, 2n)) — the in_layer / cond_layer bias gradient
   int B, L, n, last, CH, tiles_per_seq, n_wg;
 };
 
@@ -767,6 +785,11 @@ __global__ __launch_bounds__(256, 3) void wn_layer_bwd_kernel(WnBwdParams p) {
   }
   __syncthreads();                                     // every wave is past its last fragment read: the ring becomes tiles
   float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
+  float* const rsum = reinterpret_cast<float*>(ldsb + 4 * WN_TILE_BYTES);      // [256] row sums of this workgroup's dg tile
+  if (p.row_sums) {
+    rsum[tid] = 0.f;
+    __syncthreads();
+  }
   float* const dg_b = p.dg + (long long)b * (2 * n) * L;
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
@@ -785,12 +808,19 @@ __global__ __launch_bounds__(256, 3) void wn_layer_bwd_kernel(WnBwdParams p) {
       gs[r] = d * t * s * (1.f - s);
     }
     wn_store_tile<0>(gt, tile, dg_b + (long long)(blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+    if (p.row_sums) wn_tile_row_sums(tile, rsum, blk * 32, rows_valid, L, tcol, lane);
     wn_store_tile<0>(gs, tile, dg_b + (long long)(n + blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+    if (p.row_sums) wn_tile_row_sums(tile, rsum, n + blk * 32, rows_valid, L, tcol, lane);
+  }
+  if (p.row_sums) {
+    __syncthreads();
+    p.row_sums[(long long)wg * 256 + tid] = rsum[tid];
   }
 }
 
 extern "C" int fst_wn_layer_bwd(const float* d_a, const float* d_out, const float* ts, const void* image, int64_t image_bytes,
-                                float* dg, int last, int B, int L, int n, int64_t numel_a, void* stream) {
+                                float* dg, float* row_sums, int64_t row_sums_rows, int last, int B, int L, int n,
+                                int64_t numel_a, void* stream) {
   FST_REQUIRE(d_out && ts && image && dg && (last || d_a), "fst_wn_layer_bwd: null operand");
   FST_REQUIRE(B > 0 && L > 0 && n > 0 && n <= 128, "fst_wn_layer_bwd: B=%d L=%d n=%d (needs n <= 128)", B, L, n);
   FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_layer_bwd: B*n*L = %d*%d*%d does not match the element count %lld "
@@ -802,9 +832,12 @@ extern "C" int fst_wn_layer_bwd(const float* d_a, const float* d_out, const floa
               "fst_wn_layer_bwd: needs L %% 4 == 0 and 16-byte aligned tensors (L=%d)", L);
   WnBwdParams p;
   p.d_a = last ? nullptr : d_a; p.d_out = d_out; p.ts = ts; p.img = static_cast<const char*>(image); p.dg = dg;
+  p.row_sums = row_sums;
   p.B = B; p.L = L; p.n = n; p.last = last ? 1 : 0; p.CH = wn_ch(n);
   p.tiles_per_seq = (L + WN_TN - 1) / WN_TN;
   p.n_wg = B * p.tiles_per_seq;
+  FST_REQUIRE(row_sums == nullptr || row_sums_rows == p.n_wg, "fst_wn_layer_bwd: row_sums has %lld rows, the launch has %d "
+              "workgroups (B x ceil(L/128))", (long long)row_sums_rows, p.n_wg);
   if (int rc = fst_allow_full_lds((const void*)wn_layer_bwd_kernel, "fst_wn_layer_bwd")) return rc;
   hipLaunchKernelGGL(wn_layer_bwd_kernel, dim3((unsigned)p.n_wg), dim3(256), WN_BW_LDS, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
@@ -888,6 +921,7 @@ struct WnDgradParams {
   const float* d_a;     // [B][n][L] residual cotangent, or null
   float* d_a_new;       // [B][n][L]
   float* d_u0;          // [B][h][L], accumulated
+  float* row_sums;      // optional [n_wg][128]: per-workgroup Σ_t d_a_new[row] — the res rows of the next res_skip bias gradient
   int B, L, n, h, dil, CHK, tiles_per_seq, n_wg;
   int nblkw;            // 32-sample column blocks of the window
   int gsw;              // bytes per 8-channel row group of the window
@@ -987,6 +1021,11 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
   }
   __syncthreads();                                     // every wave is past its last fragment read: the ring becomes tiles
   float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
+  float* const rsum = reinterpret_cast<float*>(ldsb + 8 * WN_TILE_BYTES);      // [128]
+  if (p.row_sums) {
+    if (tid < 128) rsum[tid] = 0.f;
+    __syncthreads();
+  }
   const int tcol = t0 + wave_n0;
   // five tiles: d_a rows of block i (operand: the incoming d_a, if any), then the d_u0 rows (operand: d_u0 itself)
   auto e_src = [&](int i) -> const float* {
@@ -1003,12 +1042,34 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
     for (int r = 0; r < 16; ++r) v[r] = acc[i][r];
     float* dst = i < 4 ? p.d_a_new + ((long long)b * n + i * 32) * L : p.d_u0 + (long long)b * p.h * L;
     wn_store_tile_add(v, eq[i & 1], tile, dst, i < 4 ? n - i * 32 : p.h, L, tcol, lane);
+    if (p.row_sums && i < 4) {
+      // the tile holds the conv part only: add the operand's row sums too (d_a_new = conv + d_a)
+      float extra[4];
+      const int rrow = lane >> 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 e = eq[i & 1][j];
+        float s4 = (e.x + e.y) + (e.z + e.w);
+        s4 += __shfl_xor(s4, 1, 64);
+        s4 += __shfl_xor(s4, 2, 64);
+        s4 += __shfl_xor(s4, 4, 64);
+        extra[j] = s4;
+      }
+      wn_tile_row_sums(tile, rsum, i * 32, n - i * 32, L, tcol, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((lane & 7) == 0 && rrow + 8 * j < n - i * 32) atomicAdd(rsum + i * 32 + rrow + 8 * j, extra[j]);
+    }
+  }
+  if (p.row_sums) {
+    __syncthreads();
+    if (tid < 128) p.row_sums[(long long)wg * 128 + tid] = rsum[tid];
   }
 }
 
 extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new,
-                                  float* d_u0, int B, int L, int n, int h, int dil, int64_t numel_a, int64_t numel_u0,
-                                  void* stream) {
+                                  float* d_u0, float* row_sums, int64_t row_sums_rows, int B, int L, int n, int h, int dil,
+                                  int64_t numel_a, int64_t numel_u0, void* stream) {
   FST_REQUIRE(dg && image && d_a_new && d_u0, "fst_wn_layer_dgrad: null operand");
   FST_REQUIRE(B > 0 && L > 0 && n > 0 && n <= 128 && h > 0 && h <= 32 && dil > 0, "fst_wn_layer_dgrad: B=%d L=%d n=%d h=%d dil=%d", B, L,
               n, h, dil);
@@ -1021,9 +1082,12 @@ extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t im
               "fst_wn_layer_dgrad: needs L %% 4 == 0 and 16-byte aligned tensors (L=%d)", L);
   WnDgradParams p;
   p.dg = dg; p.img = static_cast<const char*>(image); p.d_a = d_a; p.d_a_new = d_a_new; p.d_u0 = d_u0;
+  p.row_sums = row_sums;
   p.B = B; p.L = L; p.n = n; p.h = h; p.dil = dil; p.CHK = (2 * n + 15) / 16;
   p.tiles_per_seq = (L + DG_TN - 1) / DG_TN;
   p.n_wg = B * p.tiles_per_seq;
+  FST_REQUIRE(row_sums == nullptr || row_sums_rows == p.n_wg, "fst_wn_layer_dgrad: row_sums has %lld rows, the launch has %d "
+              "workgroups (B x ceil(L/256))", (long long)row_sums_rows, p.n_wg);
   p.nblkw = (DG_TN + 2 * dil + 3 + 31) / 32;
   p.gsw = p.nblkw * 1024 + 128;
   p.slot = DG_A_BYTES + 2 * p.gsw;
@@ -1032,7 +1096,7 @@ extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t im
   const int NI = DG_A_BLOCKS * 2 + 2 * p.nblkw;
   FST_REQUIRE(((NI + 7) / 8) * (p.ns - 1) <= 16, "fst_wn_layer_dgrad: %d pieces per stage exceed the counted-wait table", NI);
   size_t lds_bytes = (size_t)p.ns * p.slot;
-  if (lds_bytes < 8 * WN_TILE_BYTES) lds_bytes = 8 * WN_TILE_BYTES;
+  if (lds_bytes < 8 * WN_TILE_BYTES + 512) lds_bytes = 8 * WN_TILE_BYTES + 512;   // tiles + the row-sum array
   if (int rc = fst_allow_full_lds((const void*)wn_layer_dgrad_kernel, "fst_wn_layer_dgrad")) return rc;
   hipLaunchKernelGGL(wn_layer_dgrad_kernel, dim3((unsigned)p.n_wg), dim3(512), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();

@@ -730,19 +730,24 @@ def wn_pack_bwd(rs_w: Tensor, n: int, last: bool) -> Tensor:
     return img
 
 
-def wn_layer_bwd(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, img: Tensor, dg: Tensor, last: bool, n: int) -> None:
+def wn_layer_bwd(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, img: Tensor, dg: Tensor, last: bool, n: int,
+                 want_row_sums: bool = False) -> Optional[Tensor]:
+    """``want_row_sums``: also returns Σ_{b,t} dg[:, row, :] ([2n]) — the in_layer / cond_layer bias gradient — from per-workgroup
+    partials the kernel leaves behind (no extra pass over dg)."""
     lib = _lib.load()
     B, _, L = d_out.shape
+    part = torch.empty(B * ((L + 127) // 128), 256, device=dg.device, dtype=torch.float32) if want_row_sums else None
     numel = _same_numel(d_out, d_a)
     for t in (ts, dg):
         if t.numel() != 2 * numel or not t.is_contiguous():
             raise ValueError("wn_layer_bwd: ts / dg must be contiguous [B, 2n, L]")
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
-    check(lib.fst_wn_layer_bwd(ptr(d_a), ptr(d_out), ptr(ts), ptr(img), img.numel() * 4, ptr(dg), int(last), B, L, n, numel,
-                               stream_ptr()), "fst_wn_layer_bwd")
+    check(lib.fst_wn_layer_bwd(ptr(d_a), ptr(d_out), ptr(ts), ptr(img), img.numel() * 4, ptr(dg), ptr(part),
+                               0 if part is None else part.size(0), int(last), B, L, n, numel, stream_ptr()), "fst_wn_layer_bwd")
     if t0 is not None:
         k = n if last else 2 * n
         KERNEL_TIMER.end("wn_layer_bwd_kernel", t0, 2.0 * B * L * n * k, 4.0 * B * L * (k + 4 * n))
+    return None if part is None else part.sum(dim=0)[: 2 * n]
 
 
 def wn_pack_dgrad(in_w: Tensor, cond_w: Tensor, n: int, h: int) -> Tensor:
@@ -762,21 +767,25 @@ def wn_pack_dgrad(in_w: Tensor, cond_w: Tensor, n: int, h: int) -> Tensor:
     return img
 
 
-def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor, n: int, h: int, dil: int) -> Tensor:
-    """returns d_a_new = d_a + W_inᵀ (*) dg;  d_u0 += W_condᵀ·dg  — one launch (csrc/wn_fused.hip)."""
+def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor, n: int, h: int, dil: int,
+                   want_row_sums: bool = False):
+    """returns d_a_new = d_a + W_inᵀ (*) dg;  d_u0 += W_condᵀ·dg  — one launch (csrc/wn_fused.hip).
+    ``want_row_sums``: returns (d_a_new, Σ_{b,t} d_a_new[:, row, :]) — the residual half of the next res_skip bias gradient."""
     lib = _lib.load()
     B, _, L = dg.shape
+    part = torch.empty(B * ((L + 255) // 256), 128, device=dg.device, dtype=torch.float32) if want_row_sums else None
     d_a_new = torch.empty(B, n, L, device=dg.device, dtype=torch.float32)
     numel = _same_numel(d_a_new, d_a)
     if dg.numel() != 2 * numel or not dg.is_contiguous() or not d_u0.is_contiguous():
         raise ValueError("wn_layer_dgrad: dg must be contiguous [B, 2n, L], d_u0 contiguous [B, h, L]")
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
-    check(lib.fst_wn_layer_dgrad(ptr(dg), ptr(img), img.numel() * 4, ptr(d_a), ptr(d_a_new), ptr(d_u0), B, L, n, h, dil, numel,
-                                 d_u0.numel(), stream_ptr()), "fst_wn_layer_dgrad")
+    check(lib.fst_wn_layer_dgrad(ptr(dg), ptr(img), img.numel() * 4, ptr(d_a), ptr(d_a_new), ptr(d_u0), ptr(part),
+                                 0 if part is None else part.size(0), B, L, n, h, dil, numel, d_u0.numel(), stream_ptr()),
+          "fst_wn_layer_dgrad")
     if t0 is not None:
         KERNEL_TIMER.end("wn_layer_dgrad_kernel", t0, 2.0 * B * L * 2 * n * (3 * n + h),
                          4.0 * B * L * (2 * n + (n if d_a is not None else 0) + n + 2 * h))
-    return d_a_new
+    return (d_a_new, part.sum(dim=0)[:n]) if want_row_sums else d_a_new
 
 
 class WNFn(torch.autograd.Function):
@@ -867,6 +876,7 @@ class WNFn(torch.autograd.Function):
         d_in_w, d_in_b, d_rs_w, d_rs_b = [None] * nl, [None] * nl, [None] * nl, [None] * nl
         d_cond_w = torch.zeros_like(cond_w) if need_w else None
         d_cond_b = torch.zeros(nl, 2 * n, device=dev, dtype=torch.float32) if need_w else None
+        d_a_sum: Optional[Tensor] = None      # Σ_{b,t} of the current d_a rows when the fused dgrad kernel left it behind
         for i in reversed(range(nl)):
             last = i == nl - 1
             # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
@@ -895,11 +905,13 @@ class WNFn(torch.autograd.Function):
                     d_rs_b[i] = d_out_sum
                 else:
                     d_rs_w[i], _ = S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul)
-                    d_rs_b[i] = torch.cat([row_sum(d_a), d_out_sum])
+                    d_rs_b[i] = torch.cat([d_a_sum if d_a_sum is not None else row_sum(d_a), d_out_sum])
             # ---- through the gate
             dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
+            dg_sum = None
             if fused_bwd:
-                wn_layer_bwd(None if last else d_a, d_out, ts_list[i], wn_pack_bwd(rs_w[i], n, last), dg, last, n)
+                dg_sum = wn_layer_bwd(None if last else d_a, d_out, ts_list[i], wn_pack_bwd(rs_w[i], n, last), dg, last, n,
+                                      want_row_sums=need_w)
             else:
                 check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]),
                                        stream_ptr()), "fst_gate_bwd")
@@ -907,18 +919,22 @@ class WNFn(torch.autograd.Function):
                 dw0, dw1 = S.ins[i].grad_w(a_list[i], u0, dg)
                 d_in_w[i] = dw0
                 d_cond_w[2 * n * i: 2 * n * (i + 1)] = dw1
-                d_in_b[i] = row_sum(dg)
+                d_in_b[i] = dg_sum if dg_sum is not None else row_sum(dg)      # fused: reduced inside the backward kernel
                 d_cond_b[i] = d_in_b[i]
             # ---- into the layer input (residual path + dilated conv) and into the conditioning input
             if ctx.fused and h <= 32 and os.environ.get("FST_WN_DGRAD", "fused") == "fused":
-                d_a = wn_layer_dgrad(dg, wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h), d_a, d_u0, n, h, 2 ** i)
+                img_d = wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h)
+                if need_w:
+                    d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i, want_row_sums=True)
+                else:
+                    d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i), None
             else:
-                d_a = S.ins[i].grad_x01(dg, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], d_a, d_u0)
+                d_a, d_a_sum = S.ins[i].grad_x01(dg, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], d_a, d_u0), None
         S.start.grad_x0(d_a, start_w, out=d_u0, flags=EPI_ACC1)
         d_start_w = d_start_b = None
         if need_w:
             d_start_w, _ = S.start.grad_w(u0, None, d_a)
-            d_start_b = row_sum(d_a)
+            d_start_b = d_a_sum if d_a_sum is not None else row_sum(d_a)
             d_cond_b = d_cond_b.reshape(-1)
         grads = [d_start_w, d_start_b, d_cond_w, d_cond_b, d_end_w, d_end_b, *d_in_w, *d_in_b, *d_rs_w, *d_rs_b]
         return (None, d_u0 if ctx.needs_input_grad[1] else None, *grads)

@@ -171,8 +171,12 @@ def test_full_batch_graph_replay_equals_eager_step():
     for k in LOSSES:
         a, b = float(rep[k]), float(eager[k])
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
+    # logit_s2t: the eval-mode classifier on the transferred features, after 11 optimisation steps from random
+    # initialisation its running statistics are far from the batch's and the logits are ~1e8: fp32-atomic sum order (the
+    # two runs differ in the last bits) is amplified to ~1e-3 there
     for k in ("logit_t", "logit_s", "logit_s2t", "w_t", "w_s", "norms_t", "norms_s"):
-        close(rep[k], eager[k], 1e-4 if k.startswith("logit") or k.startswith("w_") else 1e-3, f"graph vs eager {k}")
+        close(rep[k], eager[k], 3e-3 if k == "logit_s2t" else (1e-4 if k.startswith("logit") or k.startswith("w_") else 1e-3),
+              f"graph vs eager {k}")
     after_eager = tr.snapshot()
     # weights whose gradient is real (not rounding noise in front of a BatchNorm): RMSprop's first-step size is
     # lr*g/sqrt(0.01 g^2) = 10*lr whatever |g|, so equal signs give equal steps

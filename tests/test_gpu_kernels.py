@@ -439,8 +439,14 @@ def test_fused_wn_layer_backward(n, B, L, last):
     want = torch.cat([dacts * s * (1 - t * t), dacts * t * s * (1 - s)], 1)
     f = lambda x: None if x is None else x.float().to(DEV).contiguous()
     dg = torch.full((B, 2 * n, L), 7.0, device=DEV)
-    ops.wn_layer_bwd(f(d_a), f(d_out), f(torch.cat([t, s], 1)), ops.wn_pack_bwd(f(rs_w), n, last), dg, last, n)
+    sums = ops.wn_layer_bwd(f(d_a), f(d_out), f(torch.cat([t, s], 1)), ops.wn_pack_bwd(f(rs_w), n, last), dg, last, n,
+                            want_row_sums=True)
     assert_close(dg, want, 1e-5 * float(dacts.abs().max()) / max(1e-6, float(want.abs().max())) + 1e-6, "dg")
+    assert_close(sums, want.sum(dim=(0, 2)), 2e-5 * float(want.abs().sum(dim=(0, 2)).max()) / max(1e-9, float(want.sum(dim=(0, 2)).abs().max())),
+                 "row sums of dg (bias gradient)")
+    dg2 = torch.empty_like(dg)
+    assert ops.wn_layer_bwd(f(d_a), f(d_out), f(torch.cat([t, s], 1)), ops.wn_pack_bwd(f(rs_w), n, last), dg2, last, n) is None
+    assert torch.equal(dg2, dg)
 
 
 def test_weight_gradient_with_product_operand(arithmetic):
@@ -505,6 +511,9 @@ def test_fused_wn_layer_data_gradient(n, h, B, L, dil, res):
     d_a_in, d_u0_in = (rnd(B, n, L) if res else None), rnd(B, h, L)
     f = lambda x: None if x is None else x.float().to(DEV).contiguous()
     d_u0 = f(d_u0_in)
-    got = ops.wn_layer_dgrad(f(dg), ops.wn_pack_dgrad(f(in_w), f(cond_w), n, h), f(d_a_in), d_u0, n, h, dil)
-    assert_close(got, da_ref + (d_a_in if res else 0), 2e-5, "d_a")
+    got, sums = ops.wn_layer_dgrad(f(dg), ops.wn_pack_dgrad(f(in_w), f(cond_w), n, h), f(d_a_in), d_u0, n, h, dil, want_row_sums=True)
+    want_da = da_ref + (d_a_in if res else 0)
+    assert_close(got, want_da, 2e-5, "d_a")
     assert_close(d_u0, du_ref + d_u0_in, 2e-5, "d_u0")
+    assert_close(sums, want_da.sum(dim=(0, 2)), 2e-5 * float(want_da.abs().sum(dim=(0, 2)).max()) / max(1e-9, float(want_da.sum(dim=(0, 2)).abs().max())),
+                 "row sums of d_a (bias gradient)")
