@@ -193,7 +193,7 @@ def north_star_extras(fst, ops, trainer, x_t, B: int, L: int):
 
 def kernel_peak(key: str) -> float:
     """Dense MFMA peak (algorithmic TFLOP/s) of the instruction a conv-engine kernel is built on."""
-    bf3 = "bf3" in key or (key.startswith("conv_wgrad_kernel") and key.rstrip(">").endswith("true"))
+    bf3 = "bf3" in key or key.startswith("wn_layer_") or (key.startswith("conv_wgrad_kernel") and key.rstrip(">").endswith("true"))
     return BF16X3_MFMA_PEAK_TFLOPS if bf3 else F32_MFMA_PEAK_TFLOPS
 
 
