@@ -21,9 +21,8 @@ def calc_coeff(iter_num, high=1.0, low=0.0, alpha=100.0, max_iter=50.0):
 
 
 def grl_hook(coeff):
-    def reverse(grad):
-        return -coeff * grad.clone()
-    return reverse
+    """Tensor hook form of the gradient reversal (the small heads in widgets.py register it on their inputs)."""
+    return lambda grad: -coeff * grad
 
 
 class RandomLayer(nn.Module):
@@ -66,35 +65,49 @@ def Entropy(input_):
     return torch.sum(-input_ * torch.log(input_ + epsilon), dim=1)
 
 
-def CDAN(input_target, input_g_from_source, prob_target, prob_g_from_source, ad_net, random_layer=None):
-    """Entropy-weighted Wasserstein-style CDAN distance (C_DAN.py:49-82), including quirk Q4: the
-    ``view(-1, 1)`` results are discarded, so ``[B] * [B, 1]`` broadcasts to ``[B, B]``."""
-    input_target = torch.flatten(input_target, 1)
-    input_g_from_source = torch.flatten(input_g_from_source, 1)
-    prob_target = torch.nn.functional.softmax(prob_target, dim=1)
-    prob_g_from_source = torch.nn.functional.softmax(prob_g_from_source, dim=1)
-    if random_layer is None:
-        fusion_target = torch.bmm(prob_target.unsqueeze(2), input_target.unsqueeze(1))
-        target_out = ad_net(fusion_target.view(-1, input_target.size(1) * prob_target.size(1)))
-        fusion_source = torch.bmm(prob_g_from_source.unsqueeze(2), input_g_from_source.unsqueeze(1))
-        g_source_out = ad_net(fusion_source.view(-1, input_g_from_source.size(1) * prob_g_from_source.size(1)))
+class _ReverseGrad(torch.autograd.Function):
+    """Identity forward, cotangent × (−coeff) backward — the gradient-reversal the reference installs with a tensor hook."""
+
+    @staticmethod
+    def forward(ctx, x, coeff: float):
+        ctx.coeff = coeff
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return -ctx.coeff * g, None
+
+
+def _critic_side(features, logits, ad_net, random_layer):
+    """One domain's half of the loss: (entropy weights w_b = 1 + e^{−H(p_b)} with reversed gradient, critic outputs [B, 1]).
+    The critic sees the random multilinear map of (flattened features, class probabilities) — or, without a random
+    layer, their full outer product p ⊗ f (C_DAN.py:57-61)."""
+    f = torch.flatten(features, 1)
+    prob = torch.softmax(logits, dim=1)
+    if random_layer is not None:
+        joint = random_layer.forward([f, prob])
     else:
-        target_out = ad_net(random_layer.forward([input_target, prob_target]))
-        g_source_out = ad_net(random_layer.forward([input_g_from_source, prob_g_from_source]))
-    entropy_target = Entropy(prob_target)
-    entropy_g_from_source = Entropy(prob_g_from_source)
-    coeff = ad_net.coeff
-    entropy_target.register_hook(grl_hook(coeff))
-    entropy_g_from_source.register_hook(grl_hook(coeff))
-    weight_target = 1.0 + torch.exp(-entropy_target)
-    weight_g_from_source = 1.0 + torch.exp(-entropy_g_from_source)
+        joint = (prob.unsqueeze(2) * f.unsqueeze(1)).reshape(f.size(0), -1)      # [B, n_class·D], class-major like the bmm
+    out = ad_net(joint)
+    weights = 1.0 + torch.exp(-_ReverseGrad.apply(Entropy(prob), ad_net.coeff))
+    return weights, out
+
+
+def _q4_sum(w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """Quirk Q4 (C_DAN.py:74-80): the reference normalises w by its detached sum S, discards the ``view(-1, 1)`` and
+    multiplies [B]·[B, 1], which broadcasts to [B, B]; the sum of that matrix is (Σ_b w_b / S)·(Σ_b out_b) — written as
+    that product here (same value, same gradients: ∂/∂w_b = Σout/S, ∂/∂out_b = Σw/S = 1)."""
     if _dist.global_batch_active():
-        return _q4_sum_global(weight_target, target_out) - _q4_sum_global(weight_g_from_source, g_source_out)
-    weight_target = weight_target / torch.sum(weight_target).detach()
-    weight_g_from_source = weight_g_from_source / torch.sum(weight_g_from_source).detach()
-    distance_target = torch.sum(weight_target * target_out)                 # [B]·[B,1] → [B,B] (Q4)
-    distance_g_from_source = torch.sum(weight_g_from_source * g_source_out)
-    return distance_target - distance_g_from_source
+        return _q4_sum_global(w, out)
+    return (torch.sum(w) / torch.sum(w).detach()) * torch.sum(out)
+
+
+def CDAN(input_target, input_g_from_source, prob_target, prob_g_from_source, ad_net, random_layer=None):
+    """Entropy-weighted Wasserstein-style CDAN distance (C_DAN.py:49-82): target side minus transferred-source side,
+    each side summed as quirk Q4 prescribes.  ``prob_*`` are logits (softmax is taken here, as in the reference)."""
+    w_t, out_t = _critic_side(input_target, prob_target, ad_net, random_layer)
+    w_g, out_g = _critic_side(input_g_from_source, prob_g_from_source, ad_net, random_layer)
+    return _q4_sum(w_t, out_t) - _q4_sum(w_g, out_g)
 
 
 def _q4_sum_global(w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:

@@ -82,15 +82,13 @@ class DimensionUnification(nn.Module):
 
 
 def init_weights(m):
-    name = m.__class__.__name__
-    if name.find('Conv2d') != -1 or name.find('ConvTranspose2d') != -1:
-        nn.init.kaiming_uniform_(m.weight)
-        nn.init.zeros_(m.bias)
-    elif name.find('BatchNorm') != -1:
-        nn.init.normal_(m.weight, 1.0, 0.02)
-        nn.init.zeros_(m.bias)
-    elif name.find('Linear') != -1:
+    """``ad_net.apply(init_weights)`` (widgets.py:84-94 of the reference): Xavier-normal Linear weights, zero biases;
+    BatchNorm layers, if a head ever holds one, N(1, 0.02) weights."""
+    if isinstance(m, nn.Linear):
         nn.init.xavier_normal_(m.weight)
+        nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+        nn.init.normal_(m.weight, 1.0, 0.02)
         nn.init.zeros_(m.bias)
 
 
