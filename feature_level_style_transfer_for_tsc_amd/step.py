@@ -237,6 +237,71 @@ class JointTrainer:
         n.time, n.cal_num_target, n.cal_num_source = snap["host"]["noise"]
         self.m["ad_net"].iter_num, self.m["fd_s"].iter_num = snap["host"]["ad"], snap["host"]["fd"]
 
+    # ------------------------------------------------------------------ trainer-state checkpoint (resume == uninterrupted)
+    def state_dict(self) -> dict:
+        """Everything one more step depends on, on the CPU: the eleven modules, all thirteen optimisers, the GradNorm
+        weights and their reference losses, NoiseTransfer's running sums and counters (Q5), the GRL call counters (Q7),
+        the fixed CDAN random matrices and WaveGlow's cached — possibly stale — inverses (Q2).  The reference keeps
+        none of this across runs (utils.py:9-25 saves the classification modules only); a captured-graph trainer that
+        cannot resume would be a gap of this build, not of the reference."""
+        cpu = lambda t: t.detach().cpu().clone()
+        cpc = self.opt_cpc
+        noise = self.m["noise"]
+        return {
+            "modules": {k: {n: cpu(v) for n, v in self.m[k].state_dict().items()} for k in self.MODULES},
+            "opts": {k: o.state_dict() for k, o in self.opts.items()},
+            "opt_w_t": self.opt_w_t.state_dict(), "opt_w_s": self.opt_w_s.state_dict(),
+            "opt_cpc": {"step": [cpu(g["step"]) for g in cpc.param_groups],
+                        "exp_avg": [[cpu(cpc.state[p]["exp_avg"]) for p in g["params"]] for g in cpc.param_groups],
+                        "exp_avg_sq": [[cpu(cpc.state[p]["exp_avg_sq"]) for p in g["params"]] for g in cpc.param_groups]},
+            "w_t": cpu(self.w_t), "w_s": cpu(self.w_s),
+            "init_t": None if self.init_t is None else cpu(self.init_t),
+            "init_s": None if self.init_s is None else cpu(self.init_s),
+            "noise": {"target_avg": cpu(noise.target_avg), "source_avg": cpu(noise.source_avg), "time": noise.time,
+                      "cal_num_target": noise.cal_num_target, "cal_num_source": noise.cal_num_source},
+            "grl": {"ad_net": self.m["ad_net"].iter_num, "fd_s": self.m["fd_s"].iter_num},
+            "random_matrix": [cpu(t) for t in self.random_layer.random_matrix],
+            "w_inverse": [cpu(c.W_inverse) if hasattr(c, "W_inverse") else None for c in self.m["nf"].convinv],
+        }
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Inverse of ``state_dict``.  A captured graph holds the old buffers' addresses only for parameters and
+        optimiser moments that are restored IN PLACE here, but re-capture after loading anyway (GRL coefficients and
+        the epoch's loss coefficients are baked into a capture)."""
+        dev = self.device
+        for k in self.MODULES:
+            self.m[k].load_state_dict({n: v.to(dev) for n, v in sd["modules"][k].items()}, strict=True)
+        for k, o in self.opts.items():
+            o.load_state_dict(sd["opts"][k])
+        self.opt_w_t.load_state_dict(sd["opt_w_t"]); self.opt_w_s.load_state_dict(sd["opt_w_s"])
+        cpc = self.opt_cpc
+        with torch.no_grad():
+            for gi, g in enumerate(cpc.param_groups):
+                g["step"].copy_(sd["opt_cpc"]["step"][gi])
+                for pi, p in enumerate(g["params"]):
+                    cpc.state[p]["exp_avg"].copy_(sd["opt_cpc"]["exp_avg"][gi][pi])
+                    cpc.state[p]["exp_avg_sq"].copy_(sd["opt_cpc"]["exp_avg_sq"][gi][pi])
+            self.w_t.copy_(sd["w_t"]); self.w_s.copy_(sd["w_s"])
+            noise = self.m["noise"]
+            noise.target_avg.copy_(sd["noise"]["target_avg"]); noise.source_avg.copy_(sd["noise"]["source_avg"])
+        noise.time, noise.cal_num_target, noise.cal_num_source = (sd["noise"][k] for k in ("time", "cal_num_target", "cal_num_source"))
+        self.init_t = None if sd["init_t"] is None else sd["init_t"].to(dev)
+        self.init_s = None if sd["init_s"] is None else sd["init_s"].to(dev)
+        self.m["ad_net"].iter_num, self.m["fd_s"].iter_num = sd["grl"]["ad_net"], sd["grl"]["fd_s"]
+        self.random_layer.random_matrix = [t.to(dev) for t in sd["random_matrix"]]
+        self.random_layer._transposed = {}
+        for c, w in zip(self.m["nf"].convinv, sd["w_inverse"]):
+            if w is not None:
+                c.W_inverse = w.to(dev)
+            elif hasattr(c, "W_inverse"):
+                del c.W_inverse
+
+    def save_state(self, path: str) -> None:
+        torch.save(self.state_dict(), path)
+
+    def load_state(self, path: str) -> None:
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False))
+
     # ------------------------------------------------------------------ forward (train_and_test.py:547-603)
     def forward_losses(self, x_t, y_t, x_s, y_s, t_samples=(None, None), noise_ratios=None):
         m = self.m

@@ -493,3 +493,38 @@ def test_inference_mode_folds_batchnorm_into_the_convs():
         clf(fe(x.to(DEV)))
     ops.KERNEL_TIMER = None
     assert sum(v["launches"] for v in timer.summary().values()) == 7
+
+
+def test_trainer_state_checkpoint_resume_equals_uninterrupted(tmp_path):
+    """JointTrainer.save_state / load_state: two steps, save, a third step — against a FRESH trainer (other initial
+    weights, no optimiser state yet) that loads the file and takes the same third step.  Everything the step depends
+    on must have travelled: optimiser moments, GradNorm weights and reference losses, NoiseTransfer's sums (Q5), the
+    GRL counters (Q7), the random matrices, the cached stale inverses of the flow (Q2)."""
+    g = load("joint_small")
+    tr = _joint_trainer(g)
+    args = [torch.tensor(g[f"s0.{k}"], device=DEV) for k in ("x_t", "y_t", "x_s", "y_s")]
+    for i in range(2):
+        tr.step(*args, epoch=0, t_samples=(2 + i, 5 - i))
+    path = str(tmp_path / "trainer_state.pt")
+    tr.save_state(path)
+    want = tr.step(*args, epoch=0, t_samples=(4, 1))
+    want_params = {k: v.detach().clone() for k, v in tr._state_tensors().items() if k.startswith("m.")}
+
+    meta = json.loads(str(g["meta"]))
+    tup = lambda lp: [[tuple(t) for t in l] for l in lp]
+    torch.manual_seed(999)                                               # a different initialisation: all of it must be replaced
+    cfg = fst.JointConfig(L_t=meta["L_t"], C_in_t=meta["C_in_t"], L_s=meta["L_s"], C_in_s=meta["C_in_s"],
+                          n_class_t=meta["ncls_t"], n_class_s=meta["ncls_s"], nf_channels=meta["nf"][2],
+                          cpc_hidden=meta["cpc"][1], cdan_dim=64, ad_hidden=32, dropout_p=0.0)
+    fresh = fst.JointTrainer(cfg, DEV, fe_t_spec=tup(meta["lp_t"]), clf_spec=tup(meta["lp_clf"]), fe_s_spec=tup(meta["lp_s"]))
+    fresh.load_state(path)
+    got = fresh.step(*args, epoch=0, t_samples=(4, 1))
+    for k in ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s"):
+        assert abs(got[k].item() - want[k].item()) <= 2e-5 * max(1.0, abs(want[k].item())), (k, got[k].item(), want[k].item())
+    close(got["w_t"], want["w_t"], 1e-5, "w_t after resume"); close(got["w_s"], want["w_s"], 1e-5, "w_s after resume")
+    close(got["logit_s2t"], want["logit_s2t"], 1e-4, "logit_s2t after resume")
+    got_params = fresh._state_tensors()
+    for k in ("m.nf.WN.0.in_layers.3.weight_v", "m.clf_t.hidden.weight", "m.ad_net.ad_layer1.weight", "m.cpc.Wk.0.weight",
+              "m.noise.apply_learnable_weight.weight"):
+        close(got_params[k], want_params[k], 2e-3, "post-step " + k)        # (ad_net: clamped to +-5e-4, rounding-level differences show)
+    assert fresh.m["noise"].time == tr.m["noise"].time and fresh.m["ad_net"].iter_num == tr.m["ad_net"].iter_num
