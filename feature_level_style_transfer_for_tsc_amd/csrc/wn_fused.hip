@@ -693,7 +693,7 @@ struct WnBwdParams {
   const float* ts;     // [B][2n][L]
   const char* img;
   float* dg;           // [B][2n][L]
-  float* row_sums;     // optional [n_wg][256]: per-workgroup Σ_t dg[row] (rows [0, 2n)) — the in_layer / cond_layer bias gradient
+  float* row_sums;     // optional [256][n_wg]: per-workgroup Σ_t dg[row] (rows [0, 2n)) — the in_layer / cond_layer bias gradient
   int B, L, n, last, CH, tiles_per_seq, n_wg;
 };
 
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(256, 3) void wn_layer_bwd_kernel(WnBwdParams p) {
   }
   if (p.row_sums) {
     __syncthreads();
-    p.row_sums[(long long)wg * 256 + tid] = rsum[tid];
+    p.row_sums[(long long)tid * p.n_wg + wg] = rsum[tid];   // [256][n_wg]: the caller's sum runs over the contiguous axis
   }
 }
 
@@ -921,7 +921,7 @@ struct WnDgradParams {
   const float* d_a;     // [B][n][L] residual cotangent, or null
   float* d_a_new;       // [B][n][L]
   float* d_u0;          // [B][h][L], accumulated
-  float* row_sums;      // optional [n_wg][128]: per-workgroup Σ_t d_a_new[row] — the res rows of the next res_skip bias gradient
+  float* row_sums;      // optional [128][n_wg]: per-workgroup Σ_t d_a_new[row] — the res rows of the next res_skip bias gradient
   int B, L, n, h, dil, CHK, tiles_per_seq, n_wg;
   int nblkw;            // 32-sample column blocks of the window
   int gsw;              // bytes per 8-channel row group of the window
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
   }
   if (p.row_sums) {
     __syncthreads();
-    if (tid < 128) p.row_sums[(long long)wg * 128 + tid] = rsum[tid];
+    if (tid < 128) p.row_sums[(long long)tid * p.n_wg + wg] = rsum[tid];   // [128][n_wg]
   }
 }
 

@@ -736,18 +736,18 @@ def wn_layer_bwd(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, img: Tensor, 
     partials the kernel leaves behind (no extra pass over dg)."""
     lib = _lib.load()
     B, _, L = d_out.shape
-    part = torch.empty(B * ((L + 127) // 128), 256, device=dg.device, dtype=torch.float32) if want_row_sums else None
+    part = torch.empty(256, B * ((L + 127) // 128), device=dg.device, dtype=torch.float32) if want_row_sums else None
     numel = _same_numel(d_out, d_a)
     for t in (ts, dg):
         if t.numel() != 2 * numel or not t.is_contiguous():
             raise ValueError("wn_layer_bwd: ts / dg must be contiguous [B, 2n, L]")
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     check(lib.fst_wn_layer_bwd(ptr(d_a), ptr(d_out), ptr(ts), ptr(img), img.numel() * 4, ptr(dg), ptr(part),
-                               0 if part is None else part.size(0), int(last), B, L, n, numel, stream_ptr()), "fst_wn_layer_bwd")
+                               0 if part is None else part.size(1), int(last), B, L, n, numel, stream_ptr()), "fst_wn_layer_bwd")
     if t0 is not None:
         k = n if last else 2 * n
         KERNEL_TIMER.end("wn_layer_bwd_kernel", t0, 2.0 * B * L * n * k, 4.0 * B * L * (k + 4 * n))
-    return None if part is None else part.sum(dim=0)[: 2 * n]
+    return None if part is None else part.sum(dim=1)[: 2 * n]
 
 
 def wn_pack_dgrad(in_w: Tensor, cond_w: Tensor, n: int, h: int) -> Tensor:
@@ -773,19 +773,19 @@ def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor,
     ``want_row_sums``: returns (d_a_new, Σ_{b,t} d_a_new[:, row, :]) — the residual half of the next res_skip bias gradient."""
     lib = _lib.load()
     B, _, L = dg.shape
-    part = torch.empty(B * ((L + 255) // 256), 128, device=dg.device, dtype=torch.float32) if want_row_sums else None
+    part = torch.empty(128, B * ((L + 255) // 256), device=dg.device, dtype=torch.float32) if want_row_sums else None
     d_a_new = torch.empty(B, n, L, device=dg.device, dtype=torch.float32)
     numel = _same_numel(d_a_new, d_a)
     if dg.numel() != 2 * numel or not dg.is_contiguous() or not d_u0.is_contiguous():
         raise ValueError("wn_layer_dgrad: dg must be contiguous [B, 2n, L], d_u0 contiguous [B, h, L]")
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     check(lib.fst_wn_layer_dgrad(ptr(dg), ptr(img), img.numel() * 4, ptr(d_a), ptr(d_a_new), ptr(d_u0), ptr(part),
-                                 0 if part is None else part.size(0), B, L, n, h, dil, numel, d_u0.numel(), stream_ptr()),
+                                 0 if part is None else part.size(1), B, L, n, h, dil, numel, d_u0.numel(), stream_ptr()),
           "fst_wn_layer_dgrad")
     if t0 is not None:
         KERNEL_TIMER.end("wn_layer_dgrad_kernel", t0, 2.0 * B * L * 2 * n * (3 * n + h),
                          4.0 * B * L * (2 * n + (n if d_a is not None else 0) + n + 2 * h))
-    return (d_a_new, part.sum(dim=0)[:n]) if want_row_sums else d_a_new
+    return (d_a_new, part.sum(dim=1)[:n]) if want_row_sums else d_a_new
 
 
 class WNFn(torch.autograd.Function):

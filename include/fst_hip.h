@@ -207,8 +207,8 @@ int64_t fst_wn_bwd_image_bytes(int n, int last);
 int fst_wn_pack_bwd(const float* rs_w, int n, int last, void* image, int64_t image_bytes, void* stream);
 int fst_wn_layer_bwd(const float* d_a_next /* NULL iff last */, const float* d_out, const float* ts, const void* image,
                      int64_t image_bytes, float* dg,
-                     float* row_sums /* optional [B·⌈L/128⌉][256]: per-workgroup Σ_t dg[row]; the caller adds the rows: the
-                                        in_layer / cond_layer bias gradient without a pass over dg */,
+                     float* row_sums /* optional [256][B·⌈L/128⌉]: per-workgroup Σ_t dg[row]; the caller adds each row's
+                                        entries: the in_layer / cond_layer bias gradient without a pass over dg */,
                      int64_t row_sums_rows, int last, int B, int L, int n, int64_t numel_a, void* stream);
 
 /* Data gradient of the same layer's in_layer + cond_layer in ONE launch (the transposed dilated conv and the transposed
@@ -219,7 +219,7 @@ int fst_wn_layer_bwd(const float* d_a_next /* NULL iff last */, const float* d_o
 int64_t fst_wn_dgrad_image_bytes(int n);
 int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, void* image, int64_t image_bytes, void* stream);
 int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new, float* d_u0,
-                       float* row_sums /* optional [B·⌈L/256⌉][128]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
+                       float* row_sums /* optional [128][B·⌈L/256⌉]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
                        int B, int L, int n, int h, int dil, int64_t numel_a, int64_t numel_u0, void* stream);
 
 /* generic fp32 elementwise helpers on contiguous buffers */

@@ -54,7 +54,7 @@ def _step_both(js, tr, batch, ts):
 
 
 # Gradient tolerances (of each module's gradient scale).
-# f32 MFMA mode: 1e-3 everywhere (measured 1e-4 and better) — THE gradient parity gate of the whole step.
+# f32 MFMA mode: measured 1e-4 and better when no unit flips.
 # Split-bf16 mode (pre-activations differ from the oracle's by ~5e-6 of their scale instead of 1e-7):
 #  * 3e-3 for modules that are not upstream of a ReLU head (measured <= 4e-4; conv biases in front of a train-mode
 #    BatchNorm have a mathematically zero gradient: Σ dy with Σ dy = 0, pure rounding residue, 2e-3 at B=3);
@@ -68,7 +68,13 @@ def _step_both(js, tr, batch, ts):
 #  * the feature extractors additionally carry the conditioning of a conv weight gradient in front of BatchNorm (dy is
 #    orthogonal to 1 and x-hat: the sum cancels to ~1/600 of Σ|dy·x|; f32 itself measures 4e-5 there, split-bf16 2.6e-3).
 _UPSTREAM_OF_RELU_HEADS = ("fe_t", "fe_s", "dimunif", "clf_t", "nf", "noise", "ad_net")
-GRAD_TOL = {"f32": {"default": 1e-3}, "bf16x3": dict({"default": 3e-3}, **{m: 5e-2 for m in _UPSTREAM_OF_RELU_HEADS})}
+# The f32 mode is not immune either (one run in ~five flipped a unit at B=4: 3e-3 on clf_t.hidden.weight): fp32 atomics in
+# the BatchNorm moment sums and the K-split random-layer GEMM move the last bits between runs of the SAME binary.  So the
+# whole-step gate is: 1e-3 (f32) / 3e-3 (split-bf16) for everything not upstream of the ReLU heads, 5e-2 upstream — an
+# indexing or layout bug shows as O(1) — and the tight gradient gates are the per-module tests (flow, extractor,
+# classifier step, every kernel against fp64), which contain no such head.
+GRAD_TOL = {"f32": dict({"default": 1e-3}, **{m: 5e-2 for m in _UPSTREAM_OF_RELU_HEADS}),
+            "bf16x3": dict({"default": 3e-3}, **{m: 5e-2 for m in _UPSTREAM_OF_RELU_HEADS})}
 
 
 @pytest.fixture(params=["bf16x3", "f32"])
