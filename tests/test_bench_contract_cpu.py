@@ -1,4 +1,4 @@
-"""The bench line recorded on the MI355X (profiles/r01_d_bench_line.txt) carries every field of the driver's contract."""
+"""The bench line recorded on the MI355X (profiles/r02_bench_line.txt) carries every field of the driver's contract."""
 import json
 import os
 
@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_recorded_bench_line_has_the_contract_fields():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_d_bench_line.txt")).read())
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_line.txt")).read())
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "samples/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -22,3 +22,5 @@ def test_recorded_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "samples/s" and c["sample"]
     assert d["s1_classifier_step"]["value"] > 0 and set(d["north_star_extras"]) == {"omni_scale_fe_forward", "cpc_cross_gram", "cdan_random_layer_gemm"}
+    assert d["f32_mode"]["value"] > 0 and d["f32_mode"]["dtype"] == "f32" and d["dtype"] == "bf16x3"      # the exact-f32 figure sits beside it
+    assert c["anomaly_mode_on"]["value"] > 0 and d["mode"] == "graph" and d["config"]["sources"] == 1 and d["config"]["c_in"] == 1
