@@ -236,7 +236,9 @@ def main() -> None:
 
     import __graft_entry__ as entry
     if rank == 0:
-        entry.build()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):                          # stdout carries the one JSON line only
+            entry.build()
     import torch.distributed as dist
     bucket = None
     if world > 1:
