@@ -79,18 +79,21 @@ class _ReverseGrad(torch.autograd.Function):
 
 
 def _critic_side(features, logits, ad_net, random_layer):
-    """One domain's half of the loss: (entropy weights w_b = 1 + e^{−H(p_b)} with reversed gradient, critic outputs [B, 1]).
-    The critic sees the random multilinear map of (flattened features, class probabilities) — or, without a random
-    layer, their full outer product p ⊗ f (C_DAN.py:57-61)."""
+    """One domain's half of the loss: (class probabilities, critic outputs [B, 1]).  The critic sees the random
+    multilinear map of (flattened features, class probabilities) — or, without a random layer, their full outer
+    product p ⊗ f (C_DAN.py:57-61)."""
     f = torch.flatten(features, 1)
     prob = torch.softmax(logits, dim=1)
     if random_layer is not None:
         joint = random_layer.forward([f, prob])
     else:
         joint = (prob.unsqueeze(2) * f.unsqueeze(1)).reshape(f.size(0), -1)      # [B, n_class·D], class-major like the bmm
-    out = ad_net(joint)
-    weights = 1.0 + torch.exp(-_ReverseGrad.apply(Entropy(prob), ad_net.coeff))
-    return weights, out
+    return prob, ad_net(joint)
+
+
+def _entropy_weights(prob, coeff: float):
+    """w_b = 1 + e^{−H(p_b)}, the entropy's gradient reversed and scaled by ``coeff`` (C_DAN.py:66-72)."""
+    return 1.0 + torch.exp(-_ReverseGrad.apply(Entropy(prob), coeff))
 
 
 def _q4_sum(w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -105,8 +108,12 @@ def _q4_sum(w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 def CDAN(input_target, input_g_from_source, prob_target, prob_g_from_source, ad_net, random_layer=None):
     """Entropy-weighted Wasserstein-style CDAN distance (C_DAN.py:49-82): target side minus transferred-source side,
     each side summed as quirk Q4 prescribes.  ``prob_*`` are logits (softmax is taken here, as in the reference)."""
-    w_t, out_t = _critic_side(input_target, prob_target, ad_net, random_layer)
-    w_g, out_g = _critic_side(input_g_from_source, prob_g_from_source, ad_net, random_layer)
+    p_t, out_t = _critic_side(input_target, prob_target, ad_net, random_layer)
+    p_g, out_g = _critic_side(input_g_from_source, prob_g_from_source, ad_net, random_layer)
+    # the critic's GRL coefficient advances with every forward call; the reference reads it once, AFTER both calls, and
+    # reverses both entropy gradients with that value (C_DAN.py:62-72) — on the first batch 0.987, not the 0 of call one
+    coeff = ad_net.coeff
+    w_t, w_g = _entropy_weights(p_t, coeff), _entropy_weights(p_g, coeff)
     return _q4_sum(w_t, out_t) - _q4_sum(w_g, out_g)
 
 

@@ -1206,7 +1206,7 @@ struct WgradParams {
 // ds_read_b32 — is split into hi / lo once, by the only wave that uses it; dy is split when it is staged, into two
 // bf16 images [M rows][32 samples] (80-byte rows: a 16-lane group's ds_read_b128 covers all 64 banks) shared by the
 // four waves.
-template <int CB, int TW, bool WIDE, bool VEC, bool BF3>
+template <int CB, int TW, bool WIDE, int VEC, bool BF3>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const int32_t* __restrict__ plan) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(TW == 32, "staging maps one half-wave to one 32-sample row");
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
   constexpr int DYB = 2 * TW + 16;                       // BF3: bytes per row of a dy image
   constexpr int DYV = MBW * 32 / 8;                      // dy floats per thread per tile
   constexpr int NREG = WIDE ? 1 : WG_ITEMS;              // staged windows per workgroup
-  constexpr int XV = WIDE ? 32 : 4;                      // x floats per thread per window
+  constexpr int XV = WIDE ? 32 : (VEC == 2 ? 5 : 4);     // x floats per thread per window (VEC 2: one float4 + the sub-shift tail)
   const PlanView pv = plan_view(plan);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -1243,10 +1243,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
 
   // per staged window: source rows, channel count, first time sample relative to the tile
   const float* reg_src[NREG];
-  int reg_cnt[NREG], reg_shift[NREG], reg_width[NREG];
+  int reg_cnt[NREG], reg_shift[NREG], reg_width[NREG], reg_sub[NREG];
   long long reg_bs[NREG];
 #pragma unroll
-  for (int r = 0; r < NREG; ++r) { reg_src[r] = nullptr; reg_cnt[r] = 0; reg_shift[r] = 0; reg_width[r] = 0; reg_bs[r] = 0; }
+  for (int r = 0; r < NREG; ++r) { reg_src[r] = nullptr; reg_cnt[r] = 0; reg_shift[r] = 0; reg_width[r] = 0; reg_bs[r] = 0; reg_sub[r] = 0; }
 #pragma unroll
   for (int i = 0; i < WG_ITEMS; ++i) {
     if (i >= nit || (i > 0 && it_region[i] == it_region[i - 1])) continue;
@@ -1259,6 +1259,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
         reg_bs[r] = p.x_bs[c[0]];
         reg_cnt[r] = c[2];
         reg_shift[r] = e[0] * dil - pv.pad_left;
+        reg_sub[r] = VEC == 2 ? (reg_shift[r] & 3) : 0;  // samples by which the window starts past a 16-byte boundary
         reg_width[r] = (e[1] - 1 - e[0]) * dil + TW;
       }
     }
@@ -1337,17 +1338,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
             x_st[r][4 * i] = v.x; x_st[r][4 * i + 1] = v.y; x_st[r][4 * i + 2] = v.z; x_st[r][4 * i + 3] = v.w;
           }
         } else {
-          const int t = tt0 + reg_shift[r] + vcol;
+          // a tap shift that is not a multiple of 4 samples: the row's eight float4 start `sub` samples early (window
+          // columns vcol-sub .. vcol-sub+3) and lanes 0..sub-1 of the row fetch the tail columns 32-sub .. 31 one by one
+          const int sub = reg_sub[r];
+          const int t = tt0 + reg_shift[r] - sub + vcol;
+          const float* rowp = reg_src[r] + ((long long)b * reg_bs[r] + (long long)vrow * L);
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (t >= 0 && t < L && vrow < reg_cnt[r]) {
-            const float* vp = reg_src[r] + ((long long)b * reg_bs[r] + (long long)vrow * L + t);
-            v = *reinterpret_cast<const float4*>(vp);
+            v = *reinterpret_cast<const float4*>(rowp + t);
             if (p.x0_mul_off) {
-              const float4 w = *reinterpret_cast<const float4*>(vp + p.x0_mul_off);
+              const float4 w = *reinterpret_cast<const float4*>(rowp + t + p.x0_mul_off);
               v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
             }
           }
           x_st[r][0] = v.x; x_st[r][1] = v.y; x_st[r][2] = v.z; x_st[r][3] = v.w;
+          if constexpr (VEC == 2) {
+            float xe = 0.f;
+            const int te = tt0 + reg_shift[r] + TW - sub + (tid & 7);
+            if ((tid & 7) < sub && te >= 0 && te < L && vrow < reg_cnt[r]) {
+              xe = rowp[te];
+              if (p.x0_mul_off) xe *= rowp[te + p.x0_mul_off];
+            }
+            x_st[r][4] = xe;
+          }
         }
       }
       return;
@@ -1429,8 +1442,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradParams p, const
             }
           }
         } else if (vrow < pv.chunk_cap) {
+          const int sub = reg_sub[r], c0 = vcol - sub;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) reg[vrow * ldw + vcol + k] = x_st[r][k];
+          for (int k = 0; k < 4; ++k)
+            if (c0 + k >= 0) reg[vrow * ldw + c0 + k] = x_st[r][k];
+          if constexpr (VEC == 2)
+            if ((tid & 7) < sub) reg[vrow * ldw + TW - sub + (tid & 7)] = x_st[r][4];
         }
       }
       return;
@@ -1671,24 +1688,19 @@ extern "C" int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, i
       const int32_t* e = pv.mg + 4 * (g * pv.n_chunks + q);
       if (e[1] > e[0] && ((e[0] * pv.dil - pv.pad_left) % 4 != 0 || ((e[1] - 1 - e[0]) * pv.dil) % 4 != 0)) starts4 = false;
     }
-  const bool vec = L % 4 == 0 && (wide ? starts4 : shifts4) && x0_bs % 4 == 0 && x1_bs % 4 == 0 && dy_bs % 4 == 0 &&
+  // (single-tap windows take any shift: the kernel starts the row's 16-byte loads `shift mod 4` samples early)
+  const bool vec = L % 4 == 0 && (wide ? starts4 : true) && x0_bs % 4 == 0 && x1_bs % 4 == 0 && dy_bs % 4 == 0 &&
                    dy2_bs % 4 == 0 && al16(x0) && al16(x1) && al16(dy) && al16(dy2);
   void (*fn)(WgradParams, const int32_t*);
-  if (bf3) {
-    if (pv.MB == 8) {
-      fn = wide ? (vec ? conv_wgrad_kernel<2, TW, true, true, true> : conv_wgrad_kernel<2, TW, true, false, true>)
-                : (vec ? conv_wgrad_kernel<2, TW, false, true, true> : conv_wgrad_kernel<2, TW, false, false, true>);
-    } else {
-      fn = wide ? (vec ? conv_wgrad_kernel<1, TW, true, true, true> : conv_wgrad_kernel<1, TW, true, false, true>)
-                : (vec ? conv_wgrad_kernel<1, TW, false, true, true> : conv_wgrad_kernel<1, TW, false, false, true>);
-    }
-  } else if (pv.MB == 8) {
-    fn = wide ? (vec ? conv_wgrad_kernel<2, TW, true, true, false> : conv_wgrad_kernel<2, TW, true, false, false>)
-              : (vec ? conv_wgrad_kernel<2, TW, false, true, false> : conv_wgrad_kernel<2, TW, false, false, false>);
-  } else {
-    fn = wide ? (vec ? conv_wgrad_kernel<1, TW, true, true, false> : conv_wgrad_kernel<1, TW, true, false, false>)
-              : (vec ? conv_wgrad_kernel<1, TW, false, true, false> : conv_wgrad_kernel<1, TW, false, false, false>);
-  }
+  // VEC: 0 dword staging, 1 16-byte staging, 2 16-byte staging of single-tap windows whose shift is not a multiple of 4
+  const int vmode = !vec ? 0 : (wide || shifts4 ? 1 : 2);
+#define FST_WGRAD_PICK(CBV, BF) \
+  (wide ? (vmode ? conv_wgrad_kernel<CBV, TW, true, 1, BF> : conv_wgrad_kernel<CBV, TW, true, 0, BF>) \
+        : (vmode == 2 ? conv_wgrad_kernel<CBV, TW, false, 2, BF> \
+                      : (vmode ? conv_wgrad_kernel<CBV, TW, false, 1, BF> : conv_wgrad_kernel<CBV, TW, false, 0, BF>)))
+  if (bf3) fn = pv.MB == 8 ? FST_WGRAD_PICK(2, true) : FST_WGRAD_PICK(1, true);
+  else fn = pv.MB == 8 ? FST_WGRAD_PICK(2, false) : FST_WGRAD_PICK(1, false);
+#undef FST_WGRAD_PICK
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)fn, "fst_conv_wgrad")) return rc;
   dim3 grid((unsigned)p.ksplit, (unsigned)(pv.n_items / WG_ITEMS), 1);

@@ -8,15 +8,19 @@
   against the restated voting block on oracle logits;
 * at the metric's full batch (B=256, L=512): capture() + replay() == step() from the same snapshot.
 """
+import contextlib
+import os
+
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
 import feature_level_style_transfer_for_tsc_amd as fst
 from oracle import restatement as R
-from test_gpu_modules import check_grads, close
+from test_gpu_modules import close, live_masks
 
 DEV = "cuda"
 LOSSES = ("nf_t", "nf_s", "ce_t", "sl_t", "ce_s", "sl_s", "cdan", "ce_s2t2s", "fd_s")
@@ -35,46 +39,82 @@ def _trainer_from(js, L_t, L_s, ncls):
     return tr
 
 
+@contextlib.contextmanager
+def _head_unit_branches(record=None, impose=None):
+    """The branch every unit of the 2-D (MLP head) ReLU / LeakyReLU layers takes — recorded from one run, or imposed on
+    another.  Gradients of a piecewise-linear network are comparable only on the same piece: a head unit whose
+    pre-activation is within rounding distance of zero (two 1024-unit layers per sample in the adversarial net) takes
+    either branch depending on the last bits, and one such unit at B = 3 moves every gradient upstream of it by percent.
+    The forward VALUE is unaffected (the pre-activation is ~0 either way), so the oracle is stepped on the piece the
+    device run was on and then compared tightly.  Convolutional ReLUs (3-D) are left alone: one unit there is one of
+    B·C·L and moves nothing measurable."""
+    relu0, leaky0 = F.relu, F.leaky_relu
+    it = iter(impose) if impose is not None else None
+
+    def relu(x, inplace=False):
+        if x.dim() != 2:
+            return relu0(x, inplace)
+        if record is not None:
+            record.append((x > 0).cpu())
+            return relu0(x, inplace)
+        m = next(it)
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return x * m.to(x.dtype)
+
+    def leaky(x, negative_slope=0.01, inplace=False):
+        if x.dim() != 2:
+            return leaky0(x, negative_slope, inplace)
+        if record is not None:
+            record.append((x > 0).cpu())
+            return leaky0(x, negative_slope, inplace)
+        m = next(it)
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return torch.where(m, x, negative_slope * x)
+
+    F.relu, F.leaky_relu = relu, leaky
+    try:
+        yield
+        if it is not None:
+            assert next(it, None) is None, "the oracle evaluated fewer head layers than the device run"
+    finally:
+        F.relu, F.leaky_relu = relu0, leaky0
+
+
 def _step_both(js, tr, batch, ts):
-    """One step of the oracle and of the HIP trainer from identical state; returns (oracle report, oracle grads,
-    trainer report, trainer grads) with the gradients taken right before the optimisers consume them."""
+    """One step of the HIP trainer and of the oracle from identical state, the oracle on the linear piece the device run
+    took in the MLP heads; returns (oracle report, oracle grads, trainer report, trainer grads) with the gradients taken
+    right before the optimisers consume them."""
     (x_t, y_t), (x_s, y_s) = batch
-    rep_o = js.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=ts)
-    want = {name: {n: p.grad.detach().numpy().copy() for n, p in P.items() if p.requires_grad and p.grad is not None}
-            for name, P in js.m.items()}
-    grads = {}
+    grads, branches = {}, []
 
     def grab():
         for name in tr.MODULES:
             grads[name] = {n: p.grad.detach().clone() for n, p in tr.m[name].named_parameters() if p.grad is not None}
     tr.on_grads_ready = grab
-    rep = tr.step(x_t.to(DEV), y_t.to(DEV), x_s.to(DEV), y_s.to(DEV), epoch=0, t_samples=ts)
+    with _head_unit_branches(record=branches):
+        rep = tr.step(x_t.to(DEV), y_t.to(DEV), x_s.to(DEV), y_s.to(DEV), epoch=0, t_samples=ts)
     tr.on_grads_ready = None
+    assert branches, "no head layer went through torch.nn.functional"
+    with _head_unit_branches(impose=branches):
+        rep_o = js.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=ts)
+    want = {name: {n: p.grad.detach().numpy().copy() for n, p in P.items() if p.requires_grad and p.grad is not None}
+            for name, P in js.m.items()}
     return rep_o, want, rep, grads
 
 
-# Gradient tolerances (of each module's gradient scale).
-# f32 MFMA mode: measured 1e-4 and better when no unit flips.
-# Split-bf16 mode (pre-activations differ from the oracle's by ~5e-6 of their scale instead of 1e-7):
-#  * 3e-3 for modules that are not upstream of a ReLU head (measured <= 4e-4; conv biases in front of a train-mode
-#    BatchNorm have a mathematically zero gradient: Σ dy with Σ dy = 0, pure rounding residue, 2e-3 at B=3);
-#  * 5e-2 for everything upstream of the adversarial MLPs (ad_net: 2 x 1024 ReLU units per sample, fd_s): with 3-4 samples
-#    per batch one unit within rounding distance of zero takes the other branch in about one run in five (the K-split
-#    fp32 atomics of the random-layer GEMM move the last bits between runs), which changes the cotangent entering the
-#    flow / extractors by ~1e-2 of its scale — tests/diag_grad_vs_oracle.py shows the pattern: ad_layer1 and every module
-#    upstream of it at 1e-2, ad_layer2/3, clf_s, probtransfer, fd_s, cpc at 1e-5, the f32 mode at 1e-6 throughout.
-#    (DESIGN.md "gradients of a ReLU network are only piecewise comparable".)  The kernels themselves are held to fp64
-#    references in tests/test_gpu_kernels.py and the flow alone to 1e-3 in test_waveglow_metric_width_vs_oracle.
-#  * the feature extractors additionally carry the conditioning of a conv weight gradient in front of BatchNorm (dy is
-#    orthogonal to 1 and x-hat: the sum cancels to ~1/600 of Σ|dy·x|; f32 itself measures 4e-5 there, split-bf16 2.6e-3).
-_UPSTREAM_OF_RELU_HEADS = ("fe_t", "fe_s", "dimunif", "clf_t", "nf", "noise", "ad_net")
-# The f32 mode is not immune either (one run in ~five flipped a unit at B=4: 3e-3 on clf_t.hidden.weight): fp32 atomics in
-# the BatchNorm moment sums and the K-split random-layer GEMM move the last bits between runs of the SAME binary.  So the
-# whole-step gate is: 1e-3 (f32) / 3e-3 (split-bf16) for everything not upstream of the ReLU heads, 5e-2 upstream — an
-# indexing or layout bug shows as O(1) — and the tight gradient gates are the per-module tests (flow, extractor,
-# classifier step, every kernel against fp64), which contain no such head.
-GRAD_TOL = {"f32": dict({"default": 1e-3}, **{m: 5e-2 for m in _UPSTREAM_OF_RELU_HEADS}),
-            "bf16x3": dict({"default": 3e-3}, **{m: 5e-2 for m in _UPSTREAM_OF_RELU_HEADS})}
+# Gradient tolerances (of each module's largest gradient), with the oracle on the device run's piece of the MLP heads
+# (_head_unit_branches).  Measured on the MI355X over the five steps below (FST_GRAD_REPORT=1 prints them):
+#  * exact-f32 MFMA mode: <= 3e-5 in all eleven modules  -> gate 1e-4.  This is the gate on the step's LOGIC (which loss
+#    reaches which parameter with which coefficient, the double backward of quirk Q3, the GRL coefficients): anything
+#    wrong there is O(1e-2) or more — it caught the critic coefficient being read before the second critic call (3e-2 on
+#    clf_t.hidden.bias).
+#  * split-bf16 mode: <= 4e-4 in the flow, the heads, the classifiers and CPC -> gate 1e-3.  The two feature extractors
+#    and the dimension unification feeding them carry the conditioning of a conv weight gradient in front of a train-mode
+#    BatchNorm: dy is orthogonal to 1 and to x-hat, so Σ dy·x cancels to 1/600 .. 1/4000 of Σ|dy·x| at 3-4 samples per
+#    batch and the 5e-6 product error of the split arithmetic is amplified by that factor: measured 2.6e-3 (B=4),
+#    1.8e-2 (B=3, configs[2] source 0) -> gate 5e-2 there, 1e-2 for dimunif (measured 3.6e-3).
+GRAD_TOL = {"f32": {"default": 1e-4},
+            "bf16x3": {"default": 1e-3, "fe_t": 5e-2, "fe_s": 5e-2, "dimunif": 1e-2}}
 
 
 @pytest.fixture(params=["bf16x3", "f32"])
@@ -96,9 +136,32 @@ def _check_step(rep_o, want, rep, grads, tr, what, math="bf16x3"):
     close(rep["norms_s"], rep_o["norms_s"], 1e-3, f"{what} GradNorm norms_s")
     close(rep["w_t"], rep_o["w_t"], 1e-4, f"{what} w_t")
     close(rep["w_s"], rep_o["w_s"], 1e-4, f"{what} w_s")
-    tol = GRAD_TOL[math]
+    tol, errs = GRAD_TOL[math], {}
     for name in tr.MODULES:
-        check_grads(tr.m[name], want[name], tol.get(name, tol["default"]), f"{what} Q3 {name} ", grads=grads[name])
+        errs[name] = _grad_err(tr.m[name], want[name], grads[name])
+    if os.environ.get("FST_GRAD_REPORT"):
+        print(f"[grad report] {what}: " + " ".join(f"{n}={e:.1e}({k})" for n, (e, k) in errs.items()))
+    for name, (e, k) in errs.items():
+        assert e <= tol.get(name, tol["default"]), f"{what} Q3 {name} grad {k}: {e:.3e} of the module's gradient scale"
+
+
+def _grad_err(module, want, grads):
+    """(largest |got − want| over the module's parameters ÷ the module's largest oracle gradient, the parameter it is at);
+    omni-scale conv weights are compared on their live taps (masked taps must be exactly 0 or the dense value)."""
+    scale = max(float(np.abs(v).max()) for v in want.values())
+    masks = live_masks(module)
+    worst = (0.0, "")
+    for k, v in want.items():
+        assert k in grads and grads[k] is not None, f"{k}: no grad"
+        got = grads[k].detach().cpu().numpy().astype(np.float64)
+        if k in masks:
+            extra = got * (1 - masks[k])
+            assert not np.any((extra != 0) & (np.abs(extra - v) > 1e-3 * scale)), f"{k}: bad masked-tap gradient"
+            got, v = got * masks[k], v * masks[k]
+        e = float(np.abs(got - v).max()) / max(scale, 1e-30)
+        if e > worst[0]:
+            worst = (e, k)
+    return worst
 
 
 @pytest.mark.parametrize("L,B,seed", [(512, 4, 512), (1024, 2, 1024)])

@@ -42,6 +42,10 @@ CASES = [  # M, C0, ntaps, dil, pad_left, C1, B, L
     (240, 120, 3, 128, 128, 25, 2, 512),
     (16, 8, 3, 4, 4, 3, 3, 70),
     (300, 33, 2, 1, 0, 0, 2, 129),
+    (240, 120, 3, 2, 2, 25, 2, 512),      # tap shifts -2 / 0 / +2: 16-byte staging that starts 2 samples early
+    (240, 120, 3, 1, 1, 25, 3, 100),      # shifts -1 / 0 / +1, a partial last 32-sample tile
+    (64, 20, 2, 1, 0, 0, 3, 128),         # one-block rows, shifts 0 / +1
+    (100, 30, 3, 3, 3, 0, 2, 64),         # shifts -3 / 0 / +3
 ]
 
 
