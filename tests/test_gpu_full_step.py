@@ -41,18 +41,23 @@ def _trainer_from(js, L_t, L_s, ncls):
 
 @contextlib.contextmanager
 def _head_unit_branches(record=None, impose=None):
-    """The branch every unit of the 2-D (MLP head) ReLU / LeakyReLU layers takes — recorded from one run, or imposed on
-    another.  Gradients of a piecewise-linear network are comparable only on the same piece: a head unit whose
-    pre-activation is within rounding distance of zero (two 1024-unit layers per sample in the adversarial net) takes
-    either branch depending on the last bits, and one such unit at B = 3 moves every gradient upstream of it by percent.
-    The forward VALUE is unaffected (the pre-activation is ~0 either way), so the oracle is stepped on the piece the
-    device run was on and then compared tightly.  Convolutional ReLUs (3-D) are left alone: one unit there is one of
-    B·C·L and moves nothing measurable."""
-    relu0, leaky0 = F.relu, F.leaky_relu
+    """The branch every unit of the ReLU / LeakyReLU layers that run as torch ops takes — the MLP heads (2-D: adversarial
+    net, feature discriminator) and the dimension unification (3-D, 512 units per (sample, channel) row) — recorded from
+    one run, or imposed on another.  Gradients of a piecewise-linear network are comparable only on the same piece: a unit
+    whose pre-activation is within rounding distance of zero takes either branch depending on the last bits, and one such
+    unit at B = 3 moves every gradient upstream of it by percent.  The forward VALUE is unaffected (the pre-activation is
+    ~0 either way), so the oracle is stepped on the piece the device run was on and then compared tightly.  The ReLUs
+    fused into the BatchNorm kernels (the omni-scale convolutions) cannot be recorded and are left alone: one element
+    there is one of B·C·L."""
+    relu0, leaky0, dimunif0 = F.relu, F.leaky_relu, R.dimension_unification
     it = iter(impose) if impose is not None else None
+    inside = [0]
+
+    def synced(x):
+        return x.dim() == 2 or record is not None or inside[0] > 0     # the device side calls F.relu only in these layers
 
     def relu(x, inplace=False):
-        if x.dim() != 2:
+        if not synced(x):
             return relu0(x, inplace)
         if record is not None:
             record.append((x > 0).cpu())
@@ -62,7 +67,7 @@ def _head_unit_branches(record=None, impose=None):
         return x * m.to(x.dtype)
 
     def leaky(x, negative_slope=0.01, inplace=False):
-        if x.dim() != 2:
+        if not synced(x):
             return leaky0(x, negative_slope, inplace)
         if record is not None:
             record.append((x > 0).cpu())
@@ -71,13 +76,22 @@ def _head_unit_branches(record=None, impose=None):
         assert m.shape == x.shape, (m.shape, x.shape)
         return torch.where(m, x, negative_slope * x)
 
+    def dimunif(*a, **k):
+        inside[0] += 1
+        try:
+            return dimunif0(*a, **k)
+        finally:
+            inside[0] -= 1
+
     F.relu, F.leaky_relu = relu, leaky
+    if impose is not None:
+        R.dimension_unification = dimunif
     try:
         yield
         if it is not None:
-            assert next(it, None) is None, "the oracle evaluated fewer head layers than the device run"
+            assert next(it, None) is None, "the oracle evaluated fewer synchronised layers than the device run"
     finally:
-        F.relu, F.leaky_relu = relu0, leaky0
+        F.relu, F.leaky_relu, R.dimension_unification = relu0, leaky0, dimunif0
 
 
 def _step_both(js, tr, batch, ts):
@@ -109,13 +123,15 @@ def _step_both(js, tr, batch, ts):
 #    reaches which parameter with which coefficient, the double backward of quirk Q3, the GRL coefficients): anything
 #    wrong there is O(1e-2) or more — it caught the critic coefficient being read before the second critic call (3e-2 on
 #    clf_t.hidden.bias).
-#  * split-bf16 mode: <= 4e-4 in the flow, the heads, the classifiers and CPC -> gate 1e-3.  The two feature extractors
-#    and the dimension unification feeding them carry the conditioning of a conv weight gradient in front of a train-mode
-#    BatchNorm: dy is orthogonal to 1 and to x-hat, so Σ dy·x cancels to 1/600 .. 1/4000 of Σ|dy·x| at 3-4 samples per
-#    batch and the 5e-6 product error of the split arithmetic is amplified by that factor: measured 2.6e-3 (B=4),
-#    1.8e-2 (B=3, configs[2] source 0) -> gate 5e-2 there, 1e-2 for dimunif (measured 3.6e-3).
+#  * split-bf16 mode: <= 3e-5 in the flow, the noise transfer, the three heads, CPC and the LSTM -> gate 1e-4 there too.
+#    Modules with convolutions in front of a train-mode BatchNorm carry the conditioning of that weight gradient: dy is
+#    orthogonal to 1 and to x-hat, so Σ dy·x cancels to 1/600 .. 1/4000 of Σ|dy·x| at 3-4 samples per batch and the 5e-6
+#    product error of the split arithmetic is amplified by that factor — classifiers: measured <= 2.0e-3 -> gate 1e-2;
+#    extractors: measured 2.6e-3 (B=4) .. 2.2e-2 (B=3, configs[2] source 3) -> gate 5e-2; the dimension unification
+#    (branches synchronised, no BatchNorm of its own): measured <= 2.5e-4 -> gate 1e-3.
+_CONV_BN = {"clf_t": 1e-2, "clf_s": 1e-2, "fe_t": 5e-2, "fe_s": 5e-2, "dimunif": 1e-3}
 GRAD_TOL = {"f32": {"default": 3e-4},
-            "bf16x3": {"default": 1e-3, "fe_t": 5e-2, "fe_s": 5e-2, "dimunif": 1e-2}}
+            "bf16x3": dict({"default": 1e-4}, **_CONV_BN)}
 
 
 @pytest.fixture(params=["bf16x3", "f32"])
@@ -139,16 +155,18 @@ def _check_step(rep_o, want, rep, grads, tr, what, math="bf16x3"):
     close(rep["w_s"], rep_o["w_s"], 1e-4, f"{what} w_s")
     tol, errs = GRAD_TOL[math], {}
     for name in tr.MODULES:
-        errs[name] = _grad_err(tr.m[name], want[name], grads[name], tol.get(name, tol["default"]))
+        errs[name] = _grad_err(tr.m[name], want[name], grads[name])
     if os.environ.get("FST_GRAD_REPORT"):
         print(f"[grad report] {what}: " + " ".join(f"{n}={e:.1e}({k})" for n, (e, k) in errs.items()))
     for name, (e, k) in errs.items():
         assert e <= tol.get(name, tol["default"]), f"{what} Q3 {name} grad {k}: {e:.3e} of the module's gradient scale"
 
 
-def _grad_err(module, want, grads, tol):
-    """(largest |got − want| over the module's parameters ÷ the module's largest oracle gradient, the parameter it is at);
-    omni-scale conv weights are compared on their live taps (masked taps must be exactly 0 or the dense value)."""
+def _grad_err(module, want, grads):
+    """(largest |got − want| over the module's parameters ÷ the module's largest oracle gradient, the parameter it is at).
+    Omni-scale conv weights: the reference's gradient is dense over the Kmax taps (it masks ``weight.data``, OS_CNN.py:67-70,
+    not the graph); layers whose masked-tap gradients nobody reads compute only the taps their row groups cover, so a
+    masked tap holds either exactly 0 (not computed) or the dense value — compared wherever it is not 0."""
     scale = max(float(np.abs(v).max()) for v in want.values())
     masks = live_masks(module)
     worst = (0.0, "")
@@ -156,9 +174,7 @@ def _grad_err(module, want, grads, tol):
         assert k in grads and grads[k] is not None, f"{k}: no grad"
         got = grads[k].detach().cpu().numpy().astype(np.float64)
         if k in masks:
-            extra = got * (1 - masks[k])
-            assert not np.any((extra != 0) & (np.abs(extra - v) > tol * scale)), f"{k}: bad masked-tap gradient"
-            got, v = got * masks[k], v * masks[k]
+            got = np.where((masks[k] == 0) & (got == 0), v, got)
         e = float(np.abs(got - v).max()) / max(scale, 1e-30)
         if e > worst[0]:
             worst = (e, k)
@@ -245,8 +261,8 @@ def test_full_batch_graph_replay_equals_eager_step():
     # initialisation its running statistics are far from the batch's and the logits are ~1e8: fp32-atomic sum order (the
     # two runs differ in the last bits) is amplified to ~1e-3 there
     for k in ("logit_t", "logit_s", "logit_s2t", "w_t", "w_s", "norms_t", "norms_s"):
-        close(rep[k], eager[k], 3e-3 if k == "logit_s2t" else (1e-4 if k.startswith("logit") or k.startswith("w_") else 1e-3),
-              f"graph vs eager {k}")
+        close(rep[k], eager[k], 3e-3 if k == "logit_s2t" else (5e-4 if k.startswith("logit") else 1e-4 if k.startswith("w_") else 1e-3),
+              f"graph vs eager {k}")                              # logit_t / logit_s: 2e-4 seen (same atomics, one step earlier)
     after_eager = tr.snapshot()
     # weights whose gradient is real (not rounding noise in front of a BatchNorm): RMSprop's first-step size is
     # lr*g/sqrt(0.01 g^2) = 10*lr whatever |g|, so equal signs give equal steps
