@@ -59,6 +59,27 @@ __device__ __forceinline__ void block_sum2(float& a, float& b) {
 
 #define CH_SPLIT 16   // blocks per channel for the (B,L) reductions
 
+// 16-byte path of the per-row kernels (L a multiple of 4, 16-byte aligned bases): a row of L/4 float4 is covered by
+// tpr = min(256, pow2ceil(L/4)) threads and a 256-thread block walks 256/tpr rows at a time, so every lane carries a
+// 16-byte load whatever L is (the dword path keeps half the block idle at L = 512 and issues 4x the loads).
+struct RowVec {
+  int shift;   // log2(threads per row)
+  int L4;      // float4 per row
+};
+static inline bool vec_ok(int L, std::initializer_list<const void*> ptrs) {
+  if (L % 4 != 0) return false;
+  for (const void* q : ptrs)
+    if (q && (reinterpret_cast<uintptr_t>(q) & 15)) return false;
+  return true;
+}
+static inline RowVec row_vec(int L) {
+  RowVec v;
+  v.L4 = L / 4;
+  v.shift = 0;
+  while ((1 << v.shift) < v.L4 && v.shift < 8) ++v.shift;
+  return v;
+}
+
 // ---------------------------------------------------------------- row sums (bias / beta gradients)
 __global__ __launch_bounds__(256) void row_sum_kernel(const float* x, long long x_bs, int B, int C, int L, float* out) {
   const int c = blockIdx.x;
@@ -71,11 +92,29 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* x, long long 
   if (threadIdx.x == 0) atomicAdd(out + c, s);
 }
 
+__global__ __launch_bounds__(256) void row_sum_vec_kernel(const float* x, long long x_bs, int B, int C, int L, float* out, RowVec rv) {
+  const int c = blockIdx.x, r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
+  float s = 0.f, dummy = 0.f;
+  for (int b = blockIdx.y + r * gridDim.y; b < B; b += rpp * gridDim.y) {
+    const float4* row = reinterpret_cast<const float4*>(x + (long long)b * x_bs + (long long)c * L);
+    for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
+      const float4 v = row[t];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+  }
+  block_sum2(s, dummy);
+  if (threadIdx.x == 0) atomicAdd(out + c, s);
+}
+
 extern "C" int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, void* stream) {
   FST_REQUIRE(x && out && B > 0 && C > 0 && L > 0, "fst_row_sum: bad arguments");
   FST_REQUIRE(B == 1 || x_bs >= (int64_t)C * L, "fst_row_sum: batch stride %lld < C*L = %lld", (long long)x_bs, (long long)C * L);
-  hipLaunchKernelGGL(row_sum_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, x,
-                     (long long)x_bs, B, C, L, out);
+  if (vec_ok(L, {x}) && x_bs % 4 == 0)
+    hipLaunchKernelGGL(row_sum_vec_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)x_bs, B, C, L, out, row_vec(L));
+  else
+    hipLaunchKernelGGL(row_sum_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)x_bs, B, C, L, out);
   FST_LAUNCH_CHECK();
   return 0;
 }
@@ -99,10 +138,32 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int B, in
   }
 }
 
+__global__ __launch_bounds__(256) void bn_stats_vec_kernel(const float* y, int B, int C, int L, float* sums, RowVec rv) {
+  const int c = blockIdx.x, r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = blockIdx.y + r * gridDim.y; b < B; b += rpp * gridDim.y) {
+    const float4* row = reinterpret_cast<const float4*>(y + ((long long)b * C + c) * L);
+    for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
+      const float4 v = row[t];
+      s1 += (v.x + v.y) + (v.z + v.w);
+      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + c, s1);
+    atomicAdd(sums + C + c, s2);
+  }
+}
+
 extern "C" int fst_bn_stats(const float* y, int B, int C, int L, float* sums, int64_t numel, void* stream) {
   FST_REQUIRE(y && sums && B > 0 && C > 0 && L > 0, "fst_bn_stats: bad arguments");
   FST_REQUIRE_EXTENT("fst_bn_stats", B, C, L, numel);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, y, B, C, L, sums);
+  if (vec_ok(L, {y}))
+    hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, y, B, C, L,
+                       sums, row_vec(L));
+  else
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, y, B, C, L, sums);
   FST_LAUNCH_CHECK();
   return 0;
 }
@@ -161,11 +222,44 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* y, const flo
   }
 }
 
+__global__ __launch_bounds__(256) void bn_apply_vec_kernel(const float* y, const float* stats, const float* res,
+                                                           const float* res_stats, float* out, int rows, int C, int L,
+                                                           int relu, RowVec rv) {
+  const int r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
+  const int bc = blockIdx.x * rpp + r;           // b*C + c
+  if (bc >= rows) return;
+  const int c = bc % C;
+  const float sc = stats[2 * C + c], sh = stats[3 * C + c];
+  float rsc = 1.f, rsh = 0.f;
+  if (res && res_stats) { rsc = res_stats[2 * C + c]; rsh = res_stats[3 * C + c]; }
+  const long long base = (long long)bc * rv.L4;
+  const float4* y4 = reinterpret_cast<const float4*>(y) + base;
+  const float4* r4 = res ? reinterpret_cast<const float4*>(res) + base : nullptr;
+  float4* o4 = reinterpret_cast<float4*>(out) + base;
+  for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
+    float4 v = y4[t];
+    v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+    if (r4) {
+      const float4 q = r4[t];
+      v.x += q.x * rsc + rsh; v.y += q.y * rsc + rsh; v.z += q.z * rsc + rsh; v.w += q.w * rsc + rsh;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    o4[t] = v;
+  }
+}
+
 extern "C" int fst_bn_apply(const float* y, const float* stats, const float* res, const float* res_stats, float* out,
                             int B, int C, int L, int relu, int64_t numel, void* stream) {
   FST_REQUIRE(y && stats && out && B > 0 && C > 0 && L > 0, "fst_bn_apply: bad arguments");
   FST_REQUIRE_EXTENT("fst_bn_apply", B, C, L, numel);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, y, stats, res, res_stats, out, C, L, relu);
+  if (vec_ok(L, {y, res, out})) {
+    const RowVec rv = row_vec(L);
+    const int rpp = 256 >> rv.shift;
+    hipLaunchKernelGGL(bn_apply_vec_kernel, dim3((B * C + rpp - 1) / rpp), dim3(256), 0, (hipStream_t)stream, y, stats, res,
+                       res_stats, out, B * C, C, L, relu, rv);
+  } else {
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, y, stats, res, res_stats, out, C, L, relu);
+  }
   FST_LAUNCH_CHECK();
   return 0;
 }
@@ -191,12 +285,48 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, con
   }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* dy, const float* y, const float* out,
+                                                                const float* stats, int B, int C, int L, int relu,
+                                                                float* red, RowVec rv) {
+  const int c = blockIdx.x, r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
+  const float mean = stats[c], invstd = stats[C + c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = blockIdx.y + r * gridDim.y; b < B; b += rpp * gridDim.y) {
+    const long long base = ((long long)b * C + c) * rv.L4;
+    const float4* dy4 = reinterpret_cast<const float4*>(dy) + base;
+    const float4* y4 = reinterpret_cast<const float4*>(y) + base;
+    const float4* o4 = reinterpret_cast<const float4*>(out) + base;
+    for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
+      float4 g = dy4[t];
+      const float4 v = y4[t];
+      if (relu) {
+        const float4 o = o4[t];
+        if (!(o.x > 0.f)) g.x = 0.f;
+        if (!(o.y > 0.f)) g.y = 0.f;
+        if (!(o.z > 0.f)) g.z = 0.f;
+        if (!(o.w > 0.f)) g.w = 0.f;
+      }
+      s1 += (g.x + g.y) + (g.z + g.w);
+      s2 += (g.x * (v.x - mean) + g.y * (v.y - mean) + g.z * (v.z - mean) + g.w * (v.w - mean)) * invstd;
+    }
+  }
+  block_sum2(s1, s2);
+  if (threadIdx.x == 0) {
+    atomicAdd(red + c, s1);
+    atomicAdd(red + C + c, s2);
+  }
+}
+
 extern "C" int fst_bn_bwd_reduce(const float* dy, const float* y, const float* out, const float* stats, int B, int C,
                                  int L, int relu, float* red, int64_t numel, void* stream) {
   FST_REQUIRE(dy && y && stats && red && (!relu || out) && B > 0 && C > 0 && L > 0, "fst_bn_bwd_reduce: bad arguments");
   FST_REQUIRE_EXTENT("fst_bn_bwd_reduce", B, C, L, numel);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, dy, y,
-                     out, stats, B, C, L, relu, red);
+  if (vec_ok(L, {dy, y, out}))
+    hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, dy,
+                       y, out, stats, B, C, L, relu, red, row_vec(L));
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, dy, y,
+                       out, stats, B, C, L, relu, red);
   FST_LAUNCH_CHECK();
   return 0;
 }
@@ -217,14 +347,54 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
   }
 }
 
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* dy, const float* y, const float* out,
+                                                               const float* stats, const float* red, float* dx, int rows,
+                                                               int C, int L, int relu, int train, float invN, RowVec rv) {
+  const int r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
+  const int bc = blockIdx.x * rpp + r;
+  if (bc >= rows) return;
+  const int c = bc % C;
+  const float mean = stats[c], invstd = stats[C + c], scale = stats[2 * C + c];
+  const float m1 = train ? red[c] * invN : 0.f, m2 = train ? red[C + c] * invN : 0.f;
+  const long long base = (long long)bc * rv.L4;
+  const float4* dy4 = reinterpret_cast<const float4*>(dy) + base;
+  const float4* y4 = reinterpret_cast<const float4*>(y) + base;
+  const float4* o4 = reinterpret_cast<const float4*>(out) + base;
+  float4* dx4 = reinterpret_cast<float4*>(dx) + base;
+  for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
+    float4 g = dy4[t];
+    const float4 v = y4[t];
+    if (relu) {
+      const float4 o = o4[t];
+      if (!(o.x > 0.f)) g.x = 0.f;
+      if (!(o.y > 0.f)) g.y = 0.f;
+      if (!(o.z > 0.f)) g.z = 0.f;
+      if (!(o.w > 0.f)) g.w = 0.f;
+    }
+    float4 d;
+    d.x = scale * (g.x - m1 - (v.x - mean) * invstd * m2);
+    d.y = scale * (g.y - m1 - (v.y - mean) * invstd * m2);
+    d.z = scale * (g.z - m1 - (v.z - mean) * invstd * m2);
+    d.w = scale * (g.w - m1 - (v.w - mean) * invstd * m2);
+    dx4[t] = d;
+  }
+}
+
 extern "C" int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
                                 float* dx, int B, int C, int L, int relu, int train, int B_total, int64_t numel,
                                 void* stream) {
   FST_REQUIRE(dy && y && stats && dx && (!relu || out) && (!train || red), "fst_bn_bwd_apply: bad arguments");
   FST_REQUIRE(B > 0 && C > 0 && L > 0 && B_total >= B, "fst_bn_bwd_apply: B=%d C=%d L=%d B_total=%d", B, C, L, B_total);
   FST_REQUIRE_EXTENT("fst_bn_bwd_apply", B, C, L, numel);     // the launch walks B (not B_total) samples
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, y, out, stats, red, dx, C, L,
-                     relu, train, 1.0f / ((float)B_total * (float)L));
+  if (vec_ok(L, {dy, y, out, dx})) {
+    const RowVec rv = row_vec(L);
+    const int rpp = 256 >> rv.shift;
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((B * C + rpp - 1) / rpp), dim3(256), 0, (hipStream_t)stream, dy, y, out,
+                       stats, red, dx, B * C, C, L, relu, train, 1.0f / ((float)B_total * (float)L), rv);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, y, out, stats, red, dx, C, L,
+                       relu, train, 1.0f / ((float)B_total * (float)L));
+  }
   FST_LAUNCH_CHECK();
   return 0;
 }

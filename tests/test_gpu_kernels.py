@@ -162,10 +162,11 @@ def test_omni_scale_layers(which, arithmetic):
     assert not bool(bad.any()), "live-only dW wrote a wrong value on a masked tap"
 
 
+@pytest.mark.parametrize("L", [70, 72, 512, 1028])      # dword path; 16-byte path with a partial, an exact and >1 row pass
 @pytest.mark.parametrize("training,relu", [(True, True), (True, False), (False, True)])
-def test_batch_norm(training, relu):
+def test_batch_norm(training, relu, L):
     g = torch.Generator().manual_seed(3)
-    B, C, L = 5, 13, 70
+    B, C = 5, 13
     y = (torch.randn(B, C, L, generator=g, dtype=torch.float64) * 2 + 0.7).requires_grad_(True)
     gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
     beta = torch.randn(C, generator=g, dtype=torch.float64, requires_grad=True)
@@ -188,9 +189,10 @@ def test_batch_norm(training, relu):
     assert_close(rvd, rv_ref, 1e-5, "running var")
 
 
-def test_bn_add_bn_relu():
+@pytest.mark.parametrize("L", [50, 52, 512])
+def test_bn_add_bn_relu(L):
     g = torch.Generator().manual_seed(4)
-    B, C, L = 4, 9, 50
+    B, C = 4, 9
     mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
     ya, yb = mk(B, C, L).requires_grad_(True), (mk(B, C, L) * 3 - 1).requires_grad_(True)
     ga, ba, gb, bb = [mk(C).requires_grad_(True) for _ in range(4)]
