@@ -55,6 +55,7 @@ static inline int plan_expected_len(const int32_t* p) {
 // Raise a kernel's dynamic-LDS limit to the full 160 KiB once (idempotent; never called again for that kernel,
 // so nothing but launches happens while a stream is being captured into a hipGraph).
 int fst_allow_full_lds(const void* fn, const char* who);
+int fst_cu_count(void);   // compute units of the current device (0 if the query fails)
 
 // Host-side sanity check of a plan against the tensor shapes a launch will touch.
 int fst_check_plan(const int32_t* plan_host, int plan_len, int M, const char* who);

@@ -25,6 +25,17 @@ int fst_allow_full_lds(const void* fn, const char* who) {
   if (n_done < 64) done[n_done++] = fn;
   return 0;
 }
+int fst_cu_count(void) {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    cached[dev] = n > 0 ? n : -1;
+  }
+  return cached[dev] > 0 ? cached[dev] : 0;
+}
 extern "C" int fst_version(void) { return FST_ABI_VERSION; }
 
 __device__ __forceinline__ float wave_sum(float v) {

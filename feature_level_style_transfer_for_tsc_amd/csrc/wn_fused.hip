@@ -942,25 +942,29 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int half = lane >> 5, l31 = lane & 31;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int wg = blockIdx.x;
-  if ((p.n_wg & 7) == 0) wg = (wg & 7) * (p.n_wg >> 3) + (wg >> 3);
-  const int b = wg / p.tiles_per_seq;
-  const int t0 = (wg - b * p.tiles_per_seq) * DG_TN;
   const int wave_n0 = wave_s * 32;
   const int L = p.L, n = p.n, CHK = p.CHK, dil = p.dil;
   const char* const zero16 = p.img + (long long)CHK * DG_A_BYTES;
-  const float* const dgb = p.dg + (long long)b * (2 * n) * L;
-  const int w_lo = t0 - dil;                           // first column any tap needs
-  const int w4 = w_lo & ~3, sub = w_lo & 3;
   const int NI = DG_A_BLOCKS * 2 + 2 * p.nblkw;        // 1-KiB pieces per stage
   const int my_pieces = (NI - wave_s + 7) >> 3;        // pieces idx = wave + 8 i < NI
   const int depth = p.ns - 1;                          // stages in flight
 
-  auto issue = [&](int c, int slot) {
+  // Workgroups are persistent: the launch has one per CU (the ring leaves room for one) and workgroup j walks the virtual
+  // ids j, j + gridDim, ...  Ids that differ by a multiple of 8 share an XCD (round-robin dispatch), so each XCD gets a
+  // contiguous run of tiles — the tiles of one sequence, which re-read each other's halo, meet in one L2.
+  auto tile_of = [&](int v, int& b, int& t0) {
+    int wg = v;
+    if ((p.n_wg & 7) == 0) wg = (wg & 7) * (p.n_wg >> 3) + (wg >> 3);
+    b = wg / p.tiles_per_seq;
+    t0 = (wg - b * p.tiles_per_seq) * DG_TN;
+    return wg;
+  };
+  auto issue = [&](int b, int t0, int c, int slot) {
     char* const sl = ldsb + slot * p.slot;
     const char* asrc = p.img + (long long)c * DG_A_BYTES;
-    const float* xb = dgb + (long long)(16 * c) * L;
+    const float* xb = p.dg + ((long long)b * (2 * n) + 16 * c) * L;
     const int c_count = min(16, 2 * n - 16 * c);
+    const int w4 = (t0 - dil) & ~3;                      // 16-byte aligned start of the window (first column any tap needs)
     for (int idx = wave_s; idx < NI; idx += 8) {         // wave-uniform trip count
       if (idx < 2 * DG_A_BLOCKS) {
         __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
@@ -976,94 +980,115 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
     }
   };
 
-  f32x16 acc[5];
+  // The epilogue's transpose tiles and row-sum array live in ring slot 0; a tile whose predecessor's epilogue is still
+  // running starts its ring at slot 1, so its first stages stream in underneath that epilogue.
+  int first_slot = 0;
+  {
+    int b, t0;
+    tile_of(blockIdx.x, b, t0);
+    for (int d = 0; d < depth && d < CHK; ++d) issue(b, t0, d, d);
+  }
+  for (int v = blockIdx.x; v < p.n_wg; v += gridDim.x) {
+    int b, t0;
+    const int wg = tile_of(v, b, t0);
+    const int sub = (t0 - dil) & 3;
+    f32x16 acc[5];
 #pragma unroll
-  for (int mb = 0; mb < 5; ++mb)
+    for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
-  for (int d = 0; d < depth && d < CHK; ++d) issue(d, d);
-  int slot = 0;
-  for (int c = 0; c < CHK; ++c) {
-    // stages still allowed in flight behind stage c: those already issued, i.e. min(depth - 1, CHK - 1 - c)
-    const int newer = min(depth - 1, CHK - 1 - c);
-    wn_wait_sw<16>(newer * my_pieces);
-    __builtin_amdgcn_s_barrier();
-    if (c + depth < CHK) issue(c + depth, (slot + depth) % p.ns);
-    const char* base = ldsb + slot * p.slot;
+    int slot = first_slot;
+    for (int c = 0; c < CHK; ++c) {
+      // stages still allowed in flight behind stage c: those already issued, i.e. min(depth - 1, CHK - 1 - c).  (After a
+      // predecessor tile the epilogue's own stores may still be in flight and count too: they are NEWER than the stage
+      // waited for, so the count is merely conservative — vmcnt retires in issue order.)
+      const int newer = min(depth - 1, CHK - 1 - c);
+      wn_wait_sw<16>(newer * my_pieces);
+      __builtin_amdgcn_s_barrier();
+      if (c + depth < CHK) issue(b, t0, c + depth, (slot + depth) % p.ns);
+      const char* base = ldsb + slot * p.slot;
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
-      const int colx = wave_n0 + l31 + (2 - tap) * dil + sub;
-      const char* bp = base + DG_A_BYTES + half * p.gsw + (colx >> 5) * 1024 + (colx & 31) * 4;
-      float v[8];
+      for (int tap = 0; tap < 3; ++tap) {
+        const int colx = wave_n0 + l31 + (2 - tap) * dil + sub;
+        const char* bp = base + DG_A_BYTES + half * p.gsw + (colx >> 5) * 1024 + (colx & 31) * 4;
+        float v8[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
-      wn_u32x4 bh4, bl4;
+        for (int j = 0; j < 8; ++j) v8[j] = *reinterpret_cast<const float*>(bp + j * 128);
+        wn_u32x4 bh4, bl4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned hh, ll;
-        wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
-        bh4[j] = hh; bl4[j] = ll;
+        for (int j = 0; j < 4; ++j) {
+          unsigned hh, ll;
+          wn_split_pair(v8[2 * j], v8[2 * j + 1], hh, ll);
+          bh4[j] = hh; bl4[j] = ll;
+        }
+        const wn_bf16x8 bh = __builtin_bit_cast(wn_bf16x8, bh4), bl = __builtin_bit_cast(wn_bf16x8, bl4);
+        const char* ab = base + (tap == 0 ? 0 : (tap == 1 ? 4 : 9)) * 2048;
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb) {
+          if (mb == 4 && tap != 1) continue;               // the d_u0 block exists on the centre tap only
+          const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + lane * 16);
+          const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + 1024 + lane * 16);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+        }
       }
-      const wn_bf16x8 bh = __builtin_bit_cast(wn_bf16x8, bh4), bl = __builtin_bit_cast(wn_bf16x8, bl4);
-      const char* ab = base + (tap == 0 ? 0 : (tap == 1 ? 4 : 9)) * 2048;
+      slot = slot + 1 == p.ns ? 0 : slot + 1;
+    }
+    __syncthreads();                                     // every wave is past its last fragment read: the ring is free
+    // the next tile's first stages go into slots 1.. while this tile's epilogue works in slot 0
+    if (v + (int)gridDim.x < p.n_wg) {
+      int bn, tn;
+      tile_of(v + gridDim.x, bn, tn);
+      for (int d = 0; d < depth && d < CHK; ++d) issue(bn, tn, d, 1 + d);
+      first_slot = 1;
+    }
+    float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
+    float* const rsum = reinterpret_cast<float*>(ldsb + 8 * WN_TILE_BYTES);      // [128]
+    if (p.row_sums) {
+      if (tid < 128) rsum[tid] = 0.f;
+      __syncthreads();
+    }
+    const int tcol = t0 + wave_n0;
+    // five tiles: d_a rows of block i (operand: the incoming d_a, if any), then the d_u0 rows (operand: d_u0 itself)
+    auto e_src = [&](int i) -> const float* {
+      return i < 4 ? (p.d_a ? p.d_a + ((long long)b * n + i * 32) * L : nullptr) : p.d_u0 + (long long)b * p.h * L;
+    };
+    auto e_rows = [&](int i) -> int { return i < 4 ? (p.d_a ? n - i * 32 : 0) : p.h; };
+    float4 eq[2][4];
+    wn_fetch_tile(eq[0], e_src(0), e_rows(0), L, tcol, lane);
 #pragma unroll
-      for (int mb = 0; mb < 5; ++mb) {
-        if (mb == 4 && tap != 1) continue;               // the d_u0 block exists on the centre tap only
-        const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + lane * 16);
-        const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + 1024 + lane * 16);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
-        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+    for (int i = 0; i < 5; ++i) {
+      if (i + 1 < 5) wn_fetch_tile(eq[(i + 1) & 1], e_src(i + 1), e_rows(i + 1), L, tcol, lane);
+      float vv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vv[r] = acc[i][r];
+      float* dst = i < 4 ? p.d_a_new + ((long long)b * n + i * 32) * L : p.d_u0 + (long long)b * p.h * L;
+      wn_store_tile_add(vv, eq[i & 1], tile, dst, i < 4 ? n - i * 32 : p.h, L, tcol, lane);
+      if (p.row_sums && i < 4) {
+        // the tile holds the conv part only: add the operand's row sums too (d_a_new = conv + d_a)
+        float extra[4];
+        const int rrow = lane >> 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 e = eq[i & 1][j];
+          float s4 = (e.x + e.y) + (e.z + e.w);
+          s4 += __shfl_xor(s4, 1, 64);
+          s4 += __shfl_xor(s4, 2, 64);
+          s4 += __shfl_xor(s4, 4, 64);
+          extra[j] = s4;
+        }
+        wn_tile_row_sums(tile, rsum, i * 32, n - i * 32, L, tcol, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((lane & 7) == 0 && rrow + 8 * j < n - i * 32) atomicAdd(rsum + i * 32 + rrow + 8 * j, extra[j]);
       }
     }
-    slot = slot + 1 == p.ns ? 0 : slot + 1;
-  }
-  __syncthreads();                                     // every wave is past its last fragment read: the ring becomes tiles
-  float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
-  float* const rsum = reinterpret_cast<float*>(ldsb + 8 * WN_TILE_BYTES);      // [128]
-  if (p.row_sums) {
-    if (tid < 128) rsum[tid] = 0.f;
-    __syncthreads();
-  }
-  const int tcol = t0 + wave_n0;
-  // five tiles: d_a rows of block i (operand: the incoming d_a, if any), then the d_u0 rows (operand: d_u0 itself)
-  auto e_src = [&](int i) -> const float* {
-    return i < 4 ? (p.d_a ? p.d_a + ((long long)b * n + i * 32) * L : nullptr) : p.d_u0 + (long long)b * p.h * L;
-  };
-  auto e_rows = [&](int i) -> int { return i < 4 ? (p.d_a ? n - i * 32 : 0) : p.h; };
-  float4 eq[2][4];
-  wn_fetch_tile(eq[0], e_src(0), e_rows(0), L, tcol, lane);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    if (i + 1 < 5) wn_fetch_tile(eq[(i + 1) & 1], e_src(i + 1), e_rows(i + 1), L, tcol, lane);
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[i][r];
-    float* dst = i < 4 ? p.d_a_new + ((long long)b * n + i * 32) * L : p.d_u0 + (long long)b * p.h * L;
-    wn_store_tile_add(v, eq[i & 1], tile, dst, i < 4 ? n - i * 32 : p.h, L, tcol, lane);
-    if (p.row_sums && i < 4) {
-      // the tile holds the conv part only: add the operand's row sums too (d_a_new = conv + d_a)
-      float extra[4];
-      const int rrow = lane >> 3;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 e = eq[i & 1][j];
-        float s4 = (e.x + e.y) + (e.z + e.w);
-        s4 += __shfl_xor(s4, 1, 64);
-        s4 += __shfl_xor(s4, 2, 64);
-        s4 += __shfl_xor(s4, 4, 64);
-        extra[j] = s4;
-      }
-      wn_tile_row_sums(tile, rsum, i * 32, n - i * 32, L, tcol, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if ((lane & 7) == 0 && rrow + 8 * j < n - i * 32) atomicAdd(rsum + i * 32 + rrow + 8 * j, extra[j]);
+    if (p.row_sums) {
+      __syncthreads();
+      if (tid < 128) p.row_sums[(long long)tid * p.n_wg + wg] = rsum[tid];   // [128][n_wg]
     }
-  }
-  if (p.row_sums) {
-    __syncthreads();
-    if (tid < 128) p.row_sums[(long long)tid * p.n_wg + wg] = rsum[tid];   // [128][n_wg]
   }
 }
 
@@ -1098,7 +1123,11 @@ extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t im
   size_t lds_bytes = (size_t)p.ns * p.slot;
   if (lds_bytes < 8 * WN_TILE_BYTES + 512) lds_bytes = 8 * WN_TILE_BYTES + 512;   // tiles + the row-sum array
   if (int rc = fst_allow_full_lds((const void*)wn_layer_dgrad_kernel, "fst_wn_layer_dgrad")) return rc;
-  hipLaunchKernelGGL(wn_layer_dgrad_kernel, dim3((unsigned)p.n_wg), dim3(512), lds_bytes, (hipStream_t)stream, p);
+  // one persistent workgroup per CU; with a ring of one slot only (never: ns >= 2) the next tile could not start early
+  int grid = p.n_wg;
+  const int cus = fst_cu_count();
+  if (cus > 0 && grid > cus && (size_t)2 * lds_bytes > 160 * 1024) grid = cus;
+  hipLaunchKernelGGL(wn_layer_dgrad_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }

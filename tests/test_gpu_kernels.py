@@ -502,7 +502,10 @@ def test_gru_recurrence_matches_torch_gru(B, S, C, t_last, dev_index):
 
 @pytest.mark.parametrize("n,h,B,L,dil,res", [(120, 25, 2, 512, 1, True), (120, 25, 2, 512, 2, True), (120, 25, 3, 512, 16, True),
                                              (120, 25, 2, 512, 128, False), (120, 25, 2, 1024, 64, True), (120, 25, 2, 200, 4, True),
-                                             (8, 3, 3, 40, 2, True), (128, 32, 1, 256, 32, False), (33, 31, 2, 132, 8, True)])
+                                             (8, 3, 3, 40, 2, True), (128, 32, 1, 256, 32, False), (33, 31, 2, 132, 8, True),
+                                             # more tiles than CUs: persistent workgroups, the next tile's first stages
+                                             # streaming in under the epilogue (3-slot ring; 2-slot ring at dilation 128)
+                                             (8, 3, 131, 1024, 2, True), (16, 5, 67, 2048, 128, True), (8, 3, 300, 500, 16, False)])
 def test_fused_wn_layer_data_gradient(n, h, B, L, dil, res):
     """fst_wn_layer_dgrad (transposed dilated 3-tap conv with one tap-merged window per 16 channels + the transposed
     conditioning 1x1 as a fifth row block) against autograd of the fp64 forward convs."""
