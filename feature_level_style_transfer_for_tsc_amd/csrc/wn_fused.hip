@@ -255,6 +255,48 @@ __device__ __forceinline__ void wn_fetch_tile(float4 (&q)[4], const float* src_r
     if (t_ok && row < rows_valid) q[j] = *reinterpret_cast<const float4*>(src_rows + (long long)row * L + t + c4);
   }
 }
+// The same four pieces as loads that ALWAYS issue (lanes outside the tile read a 16-byte block of zeros instead of being
+// masked off): a caller that counts its outstanding memory operations for s_waitcnt vmcnt(N) needs the number of loads in
+// flight to be a constant, not a function of which lanes are inside the tensor.
+__device__ __forceinline__ void wn_fetch_tile_counted(float4 (&q)[4], const float* src_rows, int rows_valid, int L, int t, int lane,
+                                                      const char* zero16) {
+  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
+  const bool t_ok = t + c4 < L;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = rrow + 8 * j;
+    const float* src = (t_ok && row < rows_valid) ? src_rows + (long long)row * L + t + c4 : reinterpret_cast<const float*>(zero16);
+    q[j] = *reinterpret_cast<const float4*>(src);
+  }
+}
+// Accumulator layout ↔ global memory directly (lane = time sample, register r = row (r&3) + 8(r>>2) + 4·half): one
+// wave-instruction moves two rows × 32 consecutive samples (two full 128-byte segments).  Sixteen dword accesses per tile
+// instead of four 16-byte ones, but no LDS transpose and — for the loads — no wait inside an epilogue: operand tiles are
+// read INTO the accumulators before the GEMM that adds to them (out = operand + A·B), so their latency hides under the
+// ring's first stages, and being older than every LDS-DMA piece they are covered by the counted waits as they stand.
+__device__ __forceinline__ void wn_acc_load(f32x16& v, const float* src_rows, int rows_valid, int L, int t, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const bool t_ok = t + l31 < L && src_rows != nullptr;
+  // one per-lane address; the row term of every access is wave-uniform (scalar offset)
+  const float* lp = src_rows + ((long long)(4 * half) * L + t + l31);
+  const int rv = rows_valid - 4 * half;                  // rows this lane half may touch: (r&3) + 8(r>>2) < rv
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2);
+    v[r] = (t_ok && row < rv) ? lp[(long long)row * L] : 0.f;
+  }
+}
+__device__ __forceinline__ void wn_acc_store(const f32x16& v, float* dst_rows, int rows_valid, int L, int t, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const bool t_ok = t + l31 < L;
+  float* lp = dst_rows + ((long long)(4 * half) * L + t + l31);
+  const int rv = rows_valid - 4 * half;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2);
+    if (t_ok && row < rv) lp[(long long)row * L] = v[r];
+  }
+}
 // ... through the wave-private tile into the accumulator layout (lane = sample, registers = rows)
 __device__ __forceinline__ void wn_tile_to_acc(float (&v)[16], const float4 (&q)[4], float* tile, int lane) {
   const int rrow = lane >> 3, c4 = (lane & 7) * 4, half = lane >> 5, l31 = lane & 31;
@@ -857,9 +899,13 @@ extern "C" int fst_wn_layer_bwd(const float* d_a, const float* d_out, const floa
 // Image: per 16-channel chunk 13 row blocks × (1 KiB hi + 1 KiB lo): [tap 0: 4 blocks of d_a rows][tap 1: 4 + the d_u0 block]
 // [tap 2: 4]; tap τ multiplies dg at t + (1 − τ)·dil.  Ring of 3 slots (2 when the window of a large dilation needs the room).
 // ------------------------------------------------------------------------------------------------
-#define DG_TN 256
+#define DG_NCB 2                                     // 32-sample column blocks per wave
+#define DG_TN (8 * 32 * DG_NCB)                       // time samples per workgroup (8 waves)
 #define DG_A_BLOCKS 13
 #define DG_A_BYTES (DG_A_BLOCKS * 2048)
+#ifndef DG_EXP
+#define DG_EXP 0   // diagnostic builds only (timing, wrong results): 1 no MFMA, 2 B pieces from the zero block, 4 A pieces from the
+#endif             // zero block, 8 no epilogue stores, 16 no epilogue tiles at all, 32 no operand loads, 64 no LDS-DMA issued at all
 
 struct WnPackDgradParams {
   const float* in_w;    // [2n][n][3]
@@ -942,11 +988,15 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int half = lane >> 5, l31 = lane & 31;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave_n0 = wave_s * 32;
+  const int wave_n0 = wave_s * (32 * DG_NCB);
   const int L = p.L, n = p.n, CHK = p.CHK, dil = p.dil;
   const char* const zero16 = p.img + (long long)CHK * DG_A_BYTES;
   const int NI = DG_A_BLOCKS * 2 + 2 * p.nblkw;        // 1-KiB pieces per stage
-  const int my_pieces = (NI - wave_s + 7) >> 3;        // pieces idx = wave + 8 i < NI
+  int my_pieces = (NI - wave_s + 7) >> 3;              // pieces idx = wave + 8 i < NI
+  if (DG_EXP & 128) {                                  // diagnostics: no A pieces at all
+    my_pieces = 0;
+    for (int idx = wave_s; idx < NI; idx += 8) my_pieces += idx >= 2 * DG_A_BLOCKS;
+  }
   const int depth = p.ns - 1;                          // stages in flight
 
   // Workgroups are persistent: the launch has one per CU (the ring leaves room for one) and workgroup j walks the virtual
@@ -965,15 +1015,17 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
     const float* xb = p.dg + ((long long)b * (2 * n) + 16 * c) * L;
     const int c_count = min(16, 2 * n - 16 * c);
     const int w4 = (t0 - dil) & ~3;                      // 16-byte aligned start of the window (first column any tap needs)
+    if (DG_EXP & 64) return;
     for (int idx = wave_s; idx < NI; idx += 8) {         // wave-uniform trip count
       if (idx < 2 * DG_A_BLOCKS) {
-        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+        if (DG_EXP & 128) continue;
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((DG_EXP & 4) ? zero16 : asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
       } else {
         const int bi = idx - 2 * DG_A_BLOCKS;
         const int gq = bi >= p.nblkw ? 1 : 0, m = bi - gq * p.nblkw;
         const int row = 8 * gq + (lane >> 3);
         const int t = w4 + 32 * m + 4 * (lane & 7);
-        const bool ok = row < c_count && t >= 0 && t < L;
+        const bool ok = row < c_count && t >= 0 && t < L && !(DG_EXP & 2);
         const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
         __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + DG_A_BYTES + gq * p.gsw + m * 1024), 16, 0, 0);
       }
@@ -983,20 +1035,26 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
   // The epilogue's transpose tiles and row-sum array live in ring slot 0; a tile whose predecessor's epilogue is still
   // running starts its ring at slot 1, so its first stages stream in underneath that epilogue.
   int first_slot = 0;
-  {
-    int b, t0;
-    tile_of(blockIdx.x, b, t0);
-    for (int d = 0; d < depth && d < CHK; ++d) issue(b, t0, d, d);
-  }
   for (int v = blockIdx.x; v < p.n_wg; v += gridDim.x) {
     int b, t0;
     const int wg = tile_of(v, b, t0);
     const int sub = (t0 - dil) & 3;
-    f32x16 acc[5];
+    // accumulators start as the tensors the products are added to: d_a rows of block i (if a residual cotangent comes
+    // in), then the d_u0 rows (accumulated in place)
+    f32x16 acc[5][DG_NCB];
 #pragma unroll
     for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+      for (int cb = 0; cb < DG_NCB; ++cb) {
+        const float* src = mb < 4 ? (p.d_a ? p.d_a + ((long long)b * n + mb * 32) * L : nullptr) : p.d_u0 + (long long)b * p.h * L;
+        const int rows = (DG_EXP & 32) ? 0 : (mb < 4 ? (p.d_a ? n - mb * 32 : 0) : p.h);
+        wn_acc_load(acc[mb][cb], src, rows, L, t0 + wave_n0 + 32 * cb, lane);
+      }
+    // first tile: the ring is primed AFTER the operand loads, which are then older than every LDS-DMA piece and covered by
+    // the counted waits as they stand (a later tile's ring was primed under its predecessor's epilogue: its first wait
+    // also waits for these loads — vmcnt retires in order — which is merely conservative)
+    if (first_slot == 0)
+      for (int d = 0; d < depth && d < CHK; ++d) issue(b, t0, d, d);
 
     int slot = first_slot;
     for (int c = 0; c < CHK; ++c) {
@@ -1010,28 +1068,38 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
       const char* base = ldsb + slot * p.slot;
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) {
-        const int colx = wave_n0 + l31 + (2 - tap) * dil + sub;
-        const char* bp = base + DG_A_BYTES + half * p.gsw + (colx >> 5) * 1024 + (colx & 31) * 4;
-        float v8[8];
+        // this wave's DG_NCB column blocks of the tap's window: the fragment of a weight block is read from LDS once and
+        // multiplied against all of them (LDS reads, 128 B/clk/CU, bound the one-column-block form of this loop)
+        wn_bf16x8 bh[DG_NCB], bl[DG_NCB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v8[j] = *reinterpret_cast<const float*>(bp + j * 128);
-        wn_u32x4 bh4, bl4;
+        for (int cb = 0; cb < DG_NCB; ++cb) {
+          const int colx = wave_n0 + 32 * cb + l31 + (2 - tap) * dil + sub;
+          const char* bp = base + DG_A_BYTES + half * p.gsw + (colx >> 5) * 1024 + (colx & 31) * 4;
+          float v8[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          unsigned hh, ll;
-          wn_split_pair(v8[2 * j], v8[2 * j + 1], hh, ll);
-          bh4[j] = hh; bl4[j] = ll;
+          for (int j = 0; j < 8; ++j) v8[j] = *reinterpret_cast<const float*>(bp + j * 128);
+          wn_u32x4 bh4, bl4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned hh, ll;
+            wn_split_pair(v8[2 * j], v8[2 * j + 1], hh, ll);
+            bh4[j] = hh; bl4[j] = ll;
+          }
+          bh[cb] = __builtin_bit_cast(wn_bf16x8, bh4); bl[cb] = __builtin_bit_cast(wn_bf16x8, bl4);
         }
-        const wn_bf16x8 bh = __builtin_bit_cast(wn_bf16x8, bh4), bl = __builtin_bit_cast(wn_bf16x8, bl4);
         const char* ab = base + (tap == 0 ? 0 : (tap == 1 ? 4 : 9)) * 2048;
 #pragma unroll
         for (int mb = 0; mb < 5; ++mb) {
           if (mb == 4 && tap != 1) continue;               // the d_u0 block exists on the centre tap only
           const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + lane * 16);
           const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + 1024 + lane * 16);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+#pragma unroll
+          for (int cb = 0; cb < DG_NCB; ++cb) {
+            if (DG_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh[cb]), "v"(bl[cb])); continue; }
+            acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cb], acc[mb][cb], 0, 0, 0);
+            acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cb], acc[mb][cb], 0, 0, 0);
+            acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cb], acc[mb][cb], 0, 0, 0);
+          }
         }
       }
       slot = slot + 1 == p.ns ? 0 : slot + 1;
@@ -1050,39 +1118,19 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
       if (tid < 128) rsum[tid] = 0.f;
       __syncthreads();
     }
-    const int tcol = t0 + wave_n0;
-    // five tiles: d_a rows of block i (operand: the incoming d_a, if any), then the d_u0 rows (operand: d_u0 itself)
-    auto e_src = [&](int i) -> const float* {
-      return i < 4 ? (p.d_a ? p.d_a + ((long long)b * n + i * 32) * L : nullptr) : p.d_u0 + (long long)b * p.h * L;
-    };
-    auto e_rows = [&](int i) -> int { return i < 4 ? (p.d_a ? n - i * 32 : 0) : p.h; };
-    float4 eq[2][4];
-    wn_fetch_tile(eq[0], e_src(0), e_rows(0), L, tcol, lane);
+    // 5 × DG_NCB tiles straight from the accumulators; the bias-gradient row sums (when asked for) go through the
+    // wave's transpose tile
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      if (i + 1 < 5) wn_fetch_tile(eq[(i + 1) & 1], e_src(i + 1), e_rows(i + 1), L, tcol, lane);
-      float vv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) vv[r] = acc[i][r];
+    for (int k = 0; k < 5 * DG_NCB; ++k) {
+      const int i = k / DG_NCB, cb = k % DG_NCB, tcol = t0 + wave_n0 + 32 * cb;
       float* dst = i < 4 ? p.d_a_new + ((long long)b * n + i * 32) * L : p.d_u0 + (long long)b * p.h * L;
-      wn_store_tile_add(vv, eq[i & 1], tile, dst, i < 4 ? n - i * 32 : p.h, L, tcol, lane);
+      const int rows = i < 4 ? n - i * 32 : p.h;
+      if (DG_EXP & 16) { if (acc[i][cb][0] == 12345.678f) dst[0] = 1.f; continue; }
+      wn_acc_store(acc[i][cb], dst, (DG_EXP & 8) ? 0 : rows, L, tcol, lane);
       if (p.row_sums && i < 4) {
-        // the tile holds the conv part only: add the operand's row sums too (d_a_new = conv + d_a)
-        float extra[4];
-        const int rrow = lane >> 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 e = eq[i & 1][j];
-          float s4 = (e.x + e.y) + (e.z + e.w);
-          s4 += __shfl_xor(s4, 1, 64);
-          s4 += __shfl_xor(s4, 2, 64);
-          s4 += __shfl_xor(s4, 4, 64);
-          extra[j] = s4;
-        }
-        wn_tile_row_sums(tile, rsum, i * 32, n - i * 32, L, tcol, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if ((lane & 7) == 0 && rrow + 8 * j < n - i * 32) atomicAdd(rsum + i * 32 + rrow + 8 * j, extra[j]);
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][cb][r];
+        wn_tile_row_sums(tile, rsum, i * 32, rows, L, tcol, lane);
       }
     }
     if (p.row_sums) {
@@ -1112,14 +1160,14 @@ extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t im
   p.tiles_per_seq = (L + DG_TN - 1) / DG_TN;
   p.n_wg = B * p.tiles_per_seq;
   FST_REQUIRE(row_sums == nullptr || row_sums_rows == p.n_wg, "fst_wn_layer_dgrad: row_sums has %lld rows, the launch has %d "
-              "workgroups (B x ceil(L/256))", (long long)row_sums_rows, p.n_wg);
+              "workgroups (B x ceil(L/512))", (long long)row_sums_rows, p.n_wg);
   p.nblkw = (DG_TN + 2 * dil + 3 + 31) / 32;
   p.gsw = p.nblkw * 1024 + 128;
   p.slot = DG_A_BYTES + 2 * p.gsw;
   p.ns = 3 * p.slot <= 160 * 1024 ? 3 : 2;
   FST_REQUIRE(2 * p.slot <= 160 * 1024, "fst_wn_layer_dgrad: dilation %d needs a %d-byte window slot: too large for LDS", dil, p.slot);
   const int NI = DG_A_BLOCKS * 2 + 2 * p.nblkw;
-  FST_REQUIRE(((NI + 7) / 8) * (p.ns - 1) <= 16, "fst_wn_layer_dgrad: %d pieces per stage exceed the counted-wait table", NI);
+  FST_REQUIRE(((NI + 7) / 8) * (p.ns - 2) <= 16, "fst_wn_layer_dgrad: %d pieces per stage exceed the counted-wait table", NI);
   size_t lds_bytes = (size_t)p.ns * p.slot;
   if (lds_bytes < 8 * WN_TILE_BYTES + 512) lds_bytes = 8 * WN_TILE_BYTES + 512;   // tiles + the row-sum array
   if (int rc = fst_allow_full_lds((const void*)wn_layer_dgrad_kernel, "fst_wn_layer_dgrad")) return rc;

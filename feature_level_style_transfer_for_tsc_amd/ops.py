@@ -767,13 +767,16 @@ def wn_pack_dgrad(in_w: Tensor, cond_w: Tensor, n: int, h: int) -> Tensor:
     return img
 
 
+WN_DGRAD_TILE = 512       # time samples per workgroup of fst_wn_layer_dgrad (the library checks the row-sum extent against it)
+
+
 def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor, n: int, h: int, dil: int,
                    want_row_sums: bool = False):
     """returns d_a_new = d_a + W_inᵀ (*) dg;  d_u0 += W_condᵀ·dg  — one launch (csrc/wn_fused.hip).
     ``want_row_sums``: returns (d_a_new, Σ_{b,t} d_a_new[:, row, :]) — the residual half of the next res_skip bias gradient."""
     lib = _lib.load()
     B, _, L = dg.shape
-    part = torch.empty(128, B * ((L + 255) // 256), device=dg.device, dtype=torch.float32) if want_row_sums else None
+    part = torch.empty(128, B * ((L + WN_DGRAD_TILE - 1) // WN_DGRAD_TILE), device=dg.device, dtype=torch.float32) if want_row_sums else None
     d_a_new = torch.empty(B, n, L, device=dg.device, dtype=torch.float32)
     numel = _same_numel(d_a_new, d_a)
     if dg.numel() != 2 * numel or not dg.is_contiguous() or not d_u0.is_contiguous():

@@ -219,7 +219,7 @@ int fst_wn_layer_bwd(const float* d_a_next /* NULL iff last */, const float* d_o
 int64_t fst_wn_dgrad_image_bytes(int n);
 int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, void* image, int64_t image_bytes, void* stream);
 int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new, float* d_u0,
-                       float* row_sums /* optional [128][B·⌈L/256⌉]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
+                       float* row_sums /* optional [128][B·⌈L/512⌉]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
                        int B, int L, int n, int h, int dil, int64_t numel_a, int64_t numel_u0, void* stream);
 
 /* generic fp32 elementwise helpers on contiguous buffers */

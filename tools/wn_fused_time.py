@@ -35,4 +35,8 @@ for dil in (1, 16, 128):
     out_s.append(f"d{dil}: {timed(lambda: ops.wn_layer_fwd(a, u0, img, ts, acts, an, out, False, False, n, h, dil)):6.1f}")
 out_s.append(f"no-acts d16: {timed(lambda: ops.wn_layer_fwd(a, u0, img, ts, None, an, out, False, False, n, h, 16)):6.1f}")
 out_s.append(f"bwd: {timed(lambda: ops.wn_layer_bwd(d_a, d_out, ts, img_b, dg, False, n)):6.1f}")
+img_d = ops.wn_pack_dgrad(r(2 * n, n, 3, k=.05), r(2 * n, h, 1, k=.1), n, h)
+d_u0 = r(B, h, L)
+for dil in (1, 16, 128):
+    out_s.append(f"dgrad d{dil}: {timed(lambda: ops.wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, dil)):6.1f}")
 print(os.path.basename(os.environ.get("FST_HIP_LIB", "libfst_hip.so")), " us  ", "  ".join(out_s))
