@@ -297,6 +297,17 @@ __device__ __forceinline__ void wn_acc_store(const f32x16& v, float* dst_rows, i
     if (t_ok && row < rv) lp[(long long)row * L] = v[r];
   }
 }
+__device__ __forceinline__ void wn_acc_store(const float (&v)[16], float* dst_rows, int rows_valid, int L, int t, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const bool t_ok = t + l31 < L;
+  float* lp = dst_rows + ((long long)(4 * half) * L + t + l31);
+  const int rv = rows_valid - 4 * half;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2);
+    if (t_ok && row < rv) lp[(long long)row * L] = v[r];
+  }
+}
 // ... through the wave-private tile into the accumulator layout (lane = sample, registers = rows)
 __device__ __forceinline__ void wn_tile_to_acc(float (&v)[16], const float4 (&q)[4], float* tile, int lane) {
   const int rrow = lane >> 3, c4 = (lane & 7) * 4, half = lane >> 5, l31 = lane & 31;
@@ -528,8 +539,6 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   // in front of k-step S1+2 can see them.
   wn_wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();                        // every wave is past its last B read: the B areas are free
-  // wave-private transpose tile inside the (now dead) B area of ring slot wave/2
-  float* const tile = reinterpret_cast<float*>(ldsb + (wave_s >> 1) * WN_SLOT + WN_A_BYTES + (wave_s & 1) * WN_TILE_BYTES);
   const int tcol = t0 + wave_n0;
   float* const ts_b = p.ts + (long long)b * (2 * n) * L;
   wn_bf16x8 bh2[8], bl2[8];
@@ -545,13 +554,21 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
       av[r] = row == n ? 1.0f : tv[r] * sv[r];         // acts[n] = 1 carries b_rs through GEMM 2 (rows > n: tanh(0)·σ(0) = 0)
     }
     const int rows_valid = (WN_EXP & 8) ? 0 : n - blk * 32;               // may be <= 0: nothing stored
-    wn_store_tile<0>(tv, tile, ts_b + (long long)(blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
-    wn_store_tile<0>(sv, tile, ts_b + (long long)(n + blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+    wn_acc_store(tv, ts_b + (long long)(blk * 32) * L, rows_valid, L, tcol, lane);
+    wn_acc_store(sv, ts_b + (long long)(n + blk * 32) * L, rows_valid, L, tcol, lane);
     if (p.acts) {
       float aw[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) aw[r] = tv[r] * sv[r];
-      wn_store_tile<0>(aw, tile, p.acts + ((long long)b * n + blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
+      wn_acc_store(aw, p.acts + ((long long)b * n + blk * 32) * L, rows_valid, L, tcol, lane);
+    }
+    // GEMM 2 accumulates onto what its rows are added to — the layer input for the residual rows (a_next = a + r), the
+    // running skip sum for the skip rows (out += r) — read here, in accumulator layout, into the two accumulators the
+    // gate has just consumed: the round trip hides under the remaining gate blocks and the first k-steps
+    {
+      const int rows_e = (WN_EXP & 16) ? 0 : n - blk * 32;
+      wn_acc_load(acc[blk], ab + (long long)(blk * 32) * L, p.last ? 0 : rows_e, L, tcol, lane);
+      wn_acc_load(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, p.first ? 0 : rows_e, L, tcol, lane);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -570,11 +587,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   WN_T(tg1);
   WN_ACC(6, tg0, tg1);                                 // drain + gate + t,s stores (issue)
 
-  // ---------------------------------------------------------------- GEMM 2: r = [W_rs | b] · [acts ; 1]
-#pragma unroll
-  for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+  // ---------------------------------------------------------------- GEMM 2: [a ; out] += [W_rs | b] · [acts ; 1]
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
     const int k = S1 + ks;
@@ -615,28 +628,12 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   WN_T(tg2);
   WN_ACC(7, tg1, tg2);                                 // GEMM 2
   // ---------------------------------------------------------------- a_next = a + r[:n];  out (+)= r[n:]
-  // eight tiles: residual block i/2 (i even: a_next = r + a) and skip block i/2 (i odd: out = r (+ out)); the operand
-  // tile of i+1 is fetched before tile i is stored
-  auto e_src = [&](int i) -> const float* {
-    const int blk = i >> 1;
-    return (i & 1) ? p.out + ((long long)b * n + blk * 32) * L : ab + (long long)(blk * 32) * L;
-  };
-  auto e_rows = [&](int i) -> int {                    // rows to fetch: none for tiles that have no operand
-    if (i & 1) return p.first ? 0 : n - (i >> 1) * 32;
-    return p.last ? 0 : n - (i >> 1) * 32;
-  };
-  float4 eq[2][4];
-  wn_fetch_tile(eq[0], e_src(0), e_rows(0), L, tcol, lane);
+  // straight from the accumulators (the operands were read into them before GEMM 2): stores only, nothing to wait for
 #pragma unroll
-  for (int i = 0; i < ((WN_EXP & 16) ? 1 : 8); ++i) {
-    if (i + 1 < 8) wn_fetch_tile(eq[(i + 1) & 1], e_src(i + 1), e_rows(i + 1), L, tcol, lane);
-    const int blk = i >> 1;
-    if (!(i & 1) && p.last) continue;                  // no residual rows on the last layer
-    float v[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = acc[(i & 1) ? blk + 4 : blk][r];
-    float* dst = ((i & 1) ? p.out : p.a_next) + ((long long)b * n + blk * 32) * L;
-    wn_store_tile_add(v, eq[i & 1], tile, dst, n - blk * 32, L, tcol, lane);
+  for (int blk = 0; blk < ((WN_EXP & 16) ? 0 : 4); ++blk) {
+    const int rows_e = n - blk * 32;
+    if (!p.last) wn_acc_store(acc[blk], p.a_next + ((long long)b * n + blk * 32) * L, rows_e, L, tcol, lane);
+    wn_acc_store(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, rows_e, L, tcol, lane);
   }
   WN_T(tg3);
   WN_ACC(8, tg2, tg3);                                 // final epilogue (issue; includes waiting for the operand loads)
