@@ -274,8 +274,10 @@ def conv_wgrad(plan: Plan, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Op
             vec = L % 4 == 0 and starts4 and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0)
                                                   for t in (x0, x1, dy, dy2))
         else:
-            vec = _vec16(plan, L, x0, x1, dy, dy2)
-        key = (f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}, {'true' if vec else 'false'}, "
+            # single-tap windows: 1 = 16-byte staging, 2 = 16-byte staging that starts (shift mod 4) samples early
+            aligned = L % 4 == 0 and all(t is None or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0) for t in (x0, x1, dy, dy2))
+            vec = 0 if not aligned else (1 if _vec16(plan, L, x0, x1, dy, dy2) else 2)
+        key = (f"conv_wgrad_kernel<{plan.MB // 4}, 32, {'true' if wide else 'false'}, {int(vec)}, "
                f"{'true' if bf3 else 'false'}>")
         if KERNEL_TIMER.detail:
             key += f" M={M} rec={plan.total_records} ksplit={ksplit}"
