@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only

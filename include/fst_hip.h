@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 4
+#define FST_ABI_VERSION 5
 
 int fst_version(void);
 const char* fst_last_error(void);
