@@ -1098,6 +1098,39 @@ class GRULastFn(torch.autograd.Function):
         return dxproj, d_w, d_b, None
 
 
+class LSTM2Fn(torch.autograd.Function):
+    """h_n of a one-layer LSTM run for TWO steps on the same input with h0 = c0 = 0 (ProbTransfer, widgets.py:46-55), given
+    the input projection ``xproj`` [B, 4H] = x·W_ihᵀ + b_ih + b_hh (torch's gate order i | f | g | o).  One launch each way
+    (csrc/lstm2.hip) instead of MIOpen's step-by-step RNN; dW_hh is one small GEMM over the saved step-2 gate gradients."""
+
+    @staticmethod
+    def forward(ctx, xproj: Tensor, w_hh: Tensor):
+        lib = _lib.load()
+        _lib.require_gpu_tensor(xproj, "xproj")
+        xproj, w_hh = xproj.contiguous(), w_hh.contiguous()
+        B, H4 = xproj.shape
+        H = H4 // 4
+        assert w_hh.shape == (H4, H)
+        h2 = torch.empty(B, H, device=xproj.device, dtype=torch.float32)
+        save = torch.empty(B, 11 * H, device=xproj.device, dtype=torch.float32)
+        check(lib.fst_lstm2_fwd(ptr(xproj), ptr(w_hh.t().contiguous()), ptr(h2), ptr(save), B, H, xproj.numel(), stream_ptr()),
+              "fst_lstm2_fwd")
+        ctx.save_for_backward(w_hh, save)
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        lib = _lib.load()
+        w_hh, save = ctx.saved_tensors
+        B, H = save.size(0), save.size(1) // 11
+        dxproj = torch.empty(B, 4 * H, device=dh2.device, dtype=torch.float32)
+        dpre2 = torch.empty(B, 4 * H, device=dh2.device, dtype=torch.float32)
+        check(lib.fst_lstm2_bwd(ptr(w_hh), ptr(save), ptr(dh2.contiguous()), ptr(dxproj), ptr(dpre2), B, H, dxproj.numel(),
+                                stream_ptr()), "fst_lstm2_bwd")
+        d_w = dpre2.t() @ save[:, 10 * H:] if ctx.needs_input_grad[1] else None       # Σ_b dpre2 ⊗ h1
+        return dxproj, d_w
+
+
 # --------------------------------------------------------------------------------------------------
 # CDAN random multilinear map: x[B, D] @ R[D, O] with R fixed
 # --------------------------------------------------------------------------------------------------

@@ -55,8 +55,15 @@ class ProbTransfer(nn.Module):
         self.model = nn.LSTM(input_size=num_of_channels, hidden_size=num_of_channels, batch_first=True)
 
     def forward(self, features_of_target_before_linear):
-        x = torch.unsqueeze(features_of_target_before_linear, 1)
-        _, (h_n, _) = self.model(torch.cat((x, x), dim=1))
+        x = features_of_target_before_linear
+        m = self.model
+        if x.is_cuda and x.dim() == 2 and m.hidden_size <= 256:
+            # both steps see the same input: one projection (b_hh is added at every step, also at step 1 where h0 = 0),
+            # then the two-step recurrence as one launch
+            xproj = torch.addmm(m.bias_ih_l0 + m.bias_hh_l0, x, m.weight_ih_l0.t())
+            return ops.LSTM2Fn.apply(xproj, m.weight_hh_l0)
+        x = torch.unsqueeze(x, 1)
+        _, (h_n, _) = m(torch.cat((x, x), dim=1))
         return torch.squeeze(h_n, dim=0)
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 5
+#define FST_ABI_VERSION 6
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -264,6 +264,18 @@ int fst_gru_fwd(const float* xproj, const float* w_hh, const float* b_hh, float*
 int fst_gru_bwd(const float* w_hh, const float* h_all, const float* gates, const float* dout,
                 const int32_t* t_last_dev, int t_last, float* dxproj, float* dgh, int B, int S, int H,
                 int64_t numel_h, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The 2-step LSTM of ProbTransfer (widgets.py:46-55: nn.LSTM(C, C, batch_first=True) over the pooled feature repeated
+ * twice, h0 = c0 = 0; only h_n is consumed), one launch per direction.  xproj [B][4H] = x·W_ihᵀ + b_ih + b_hh (gate order
+ * i | f | g | o, torch's; the same projection feeds both steps).  Forward: w_hh_t = W_hhᵀ [H][4H]; writes h2 [B][H] and
+ * save [B][11H] = gates of step 1 | gates of step 2 | c1 | c2 | h1.  Backward: dh2 [B][H] = d loss / d h_n; writes
+ * dxproj [B][4H] (→ d x, dW_ih, db_ih = db_hh by GEMMs outside) and dpre2 [B][4H] (dW_hh = Σ_b dpre2 ⊗ h1, h1 = save[..., 10H:]).
+ * H <= 256.  numel_xproj = element count of the [B][4H] tensors as the caller holds them.
+ * ------------------------------------------------------------------------------------------- */
+int fst_lstm2_fwd(const float* xproj, const float* w_hh_t, float* h2, float* save, int B, int H, int64_t numel_xproj, void* stream);
+int fst_lstm2_bwd(const float* w_hh, const float* save, const float* dh2, float* dxproj, float* dpre2, int B, int H,
+                  int64_t numel_xproj, void* stream);
 
 #ifdef __cplusplus
 }

@@ -500,6 +500,28 @@ def test_gru_recurrence_matches_torch_gru(B, S, C, t_last, dev_index):
     assert float(xd.grad[:, t_last + 1:].abs().max()) == 0.0 if t_last + 1 < S else True      # steps beyond t_last: no gradient
 
 
+@pytest.mark.parametrize("B,H", [(5, 50), (256, 175), (3, 256), (2, 7)])
+def test_two_step_lstm_matches_torch_lstm(B, H):
+    """fst_lstm2_fwd / _bwd (ProbTransfer: nn.LSTM over the pooled feature repeated twice, h_n) against torch.nn.LSTM in
+    fp64 — output and every gradient (input, W_ih, W_hh, both biases)."""
+    from feature_level_style_transfer_for_tsc_amd.widgets import ProbTransfer
+    torch.manual_seed(H + B)
+    ref = torch.nn.LSTM(H, H, batch_first=True).double()
+    x = torch.randn(B, H, dtype=torch.float64, requires_grad=True)
+    _, (h_n, _) = ref(torch.stack([x, x], dim=1))
+    w = torch.randn(B, H, dtype=torch.float64)
+    (h_n[0] * w).sum().backward()
+    pt = ProbTransfer(H).to(DEV)
+    pt.model.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    xd = x.detach().float().to(DEV).requires_grad_(True)
+    out = pt(xd)
+    (out * w.float().to(DEV)).sum().backward()
+    assert_close(out, h_n[0], 1e-5, "h_n")
+    assert_close(xd.grad, x.grad, 2e-5, "dx")
+    for name in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+        assert_close(getattr(pt.model, name).grad, getattr(ref, name).grad, 2e-5, name)
+
+
 @pytest.mark.parametrize("n,h,B,L,dil,res", [(120, 25, 2, 512, 1, True), (120, 25, 2, 512, 2, True), (120, 25, 3, 512, 16, True),
                                              (120, 25, 2, 512, 128, False), (120, 25, 2, 1024, 64, True), (120, 25, 2, 200, 4, True),
                                              (8, 3, 3, 40, 2, True), (128, 32, 1, 256, 32, False), (33, 31, 2, 132, 8, True),
