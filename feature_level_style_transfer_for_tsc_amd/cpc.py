@@ -75,6 +75,9 @@ class CPC(nn.Module):
             c_t = output[:, t_samples, :].reshape(B, self.hidden_dim)
         t0 = (t_samples + 1).to(torch.int32) if dev_t else t_samples + 1
         W, b = self._stacked()
-        pred = torch.baddbmm(b.unsqueeze(1), c_t.unsqueeze(0).expand(T, B, -1), W.transpose(1, 2))   # [T, B, C]
+        # predᵀ[i] = W_i·c_tᵀ + b_i: with W as the LEFT operand its gradient dpredᵀ·c_t comes out contiguous [T, C, H], so the
+        # stack's backward hands every Wk[i] a slice autograd can keep as it is (as the right operand the gradient is a
+        # transposed view and each of the T = L/2 predictors costs a strided clone: 256 launches per CPC call)
+        pred = torch.baddbmm(b.unsqueeze(2), W, c_t.t().unsqueeze(0).expand(T, -1, -1)).transpose(1, 2)   # [T, B, C]
         # global-batch data parallelism: the negatives of a row are the predictions of EVERY rank's samples
         return ops.CPCNceFn.apply(features, _dist.gather_cat(pred, 1), t0, T, _dist.rank() * B)

@@ -506,8 +506,9 @@ class ConvSpec:
         return out
 
     def grad_w(self, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor] = None,
-               msplit: Optional[int] = None, x0_mul_off: int = 0) -> Tuple[Tensor, Optional[Tensor]]:
-        """``x0_mul_off``: the x operand is x0[i]·x0[i + x0_mul_off] (x0 = a row slice of the saved gate halves)."""
+               msplit: Optional[int] = None, x0_mul_off: int = 0, out1: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+        """``x0_mul_off``: the x operand is x0[i]·x0[i + x0_mul_off] (x0 = a row slice of the saved gate halves).
+        ``out1``: a contiguous [M, C1, 1] tensor (e.g. a row slice of a stacked gradient) that receives dw1 in place."""
         B, L = x0.size(0), x0.size(2)
         plan = self.wg_plan()
         n_wg = max(1, len(plan.items()) // 4)
@@ -516,7 +517,13 @@ class ConvSpec:
         # a dense plan (every tap of every row) makes unpack write every element: no zero fill needed
         alloc = torch.empty if (self.dense_dw or self.row_live is None) else torch.zeros
         dw0 = alloc(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
-        dw1 = alloc(self.M, self.C1, 1, device=x0.device, dtype=torch.float32) if self.C1 else None
+        dw1 = None
+        if self.C1:
+            if out1 is not None:
+                assert out1.shape == (self.M, self.C1, 1) and out1.is_contiguous() and out1.dtype == torch.float32
+                dw1 = out1                                # (a zero-filled target when the plan does not write every element)
+            else:
+                dw1 = alloc(self.M, self.C1, 1, device=x0.device, dtype=torch.float32)
         unpack_weights(plan, self.M, da, dw0, self.s_w0(), dw1, self.s_w1())
         return dw0, dw1
 
@@ -880,7 +887,7 @@ class WNFn(torch.autograd.Function):
         d_a: Optional[Tensor] = None
         d_in_w, d_in_b, d_rs_w, d_rs_b = [None] * nl, [None] * nl, [None] * nl, [None] * nl
         d_cond_w = torch.zeros_like(cond_w) if need_w else None
-        d_cond_b = torch.zeros(nl, 2 * n, device=dev, dtype=torch.float32) if need_w else None
+        d_cond_b = None
         d_a_sum: Optional[Tensor] = None      # Σ_{b,t} of the current d_a rows when the fused dgrad kernel left it behind
         for i in reversed(range(nl)):
             last = i == nl - 1
@@ -921,11 +928,9 @@ class WNFn(torch.autograd.Function):
                 check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]),
                                        stream_ptr()), "fst_gate_bwd")
             if need_w:
-                dw0, dw1 = S.ins[i].grad_w(a_list[i], u0, dg)
-                d_in_w[i] = dw0
-                d_cond_w[2 * n * i: 2 * n * (i + 1)] = dw1
+                # the layer's rows of the stacked cond_layer gradient are written in place by the unpack
+                d_in_w[i], _ = S.ins[i].grad_w(a_list[i], u0, dg, out1=d_cond_w[2 * n * i: 2 * n * (i + 1)])
                 d_in_b[i] = dg_sum if dg_sum is not None else row_sum(dg)      # fused: reduced inside the backward kernel
-                d_cond_b[i] = d_in_b[i]
             # ---- into the layer input (residual path + dilated conv) and into the conditioning input
             if ctx.fused and h <= 32 and os.environ.get("FST_WN_DGRAD", "fused") == "fused":
                 img_d = wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h)
@@ -940,7 +945,7 @@ class WNFn(torch.autograd.Function):
         if need_w:
             d_start_w, _ = S.start.grad_w(u0, None, d_a)
             d_start_b = d_a_sum if d_a_sum is not None else row_sum(d_a)
-            d_cond_b = d_cond_b.reshape(-1)
+            d_cond_b = torch.cat(d_in_b)                                       # cond_layer bias = the in_layer biases, stacked
         grads = [d_start_w, d_start_b, d_cond_w, d_cond_b, d_end_w, d_end_b, *d_in_w, *d_in_b, *d_rs_w, *d_rs_b]
         return (None, d_u0 if ctx.needs_input_grad[1] else None, *grads)
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostics: which Python call sites issue the most aten ops in one eager joint step (metric config)."""
+"""Diagnostics: the small aten ops of one eager joint step (metric config), counted per input shape."""
 import os, sys, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,13 +13,12 @@ x_t, y_t = synthetic_batch(B, 1, L, 4, dev, 1000); x_s, y_s = synthetic_batch(B,
 for _ in range(2):
     tr.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=(10, 20))
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
     tr.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=(10, 20))
-tab = prof.key_averages(group_by_stack_n=8)
 rows = []
-for ev in tab:
-    if ev.key in ("aten::div", "aten::div_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::copy_"):
-        rows.append((ev.count, ev.key, [s for s in ev.stack if "site-packages/torch/autograd" not in s][:6]))
+for ev in prof.key_averages(group_by_input_shape=True):
+    if ev.key in ("aten::div", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::copy_", "aten::sum", "aten::cat", "aten::mul"):
+        rows.append((ev.count, ev.key, str(ev.input_shapes)[:150]))
 rows.sort(key=lambda r: -r[0])
-for c, k, st in rows[:28]:
-    print(f"{c:5d} {k:12s} " + " <- ".join(x.split("/")[-1][:60] for x in st[:4]))
+for c, k, sh in rows[:60]:
+    print(f"{c:5d} {k:12s} {sh}")
