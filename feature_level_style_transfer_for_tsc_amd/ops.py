@@ -780,9 +780,10 @@ WN_DGRAD_TILE = 512       # time samples per workgroup of fst_wn_layer_dgrad (th
 
 
 def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor, n: int, h: int, dil: int,
-                   want_row_sums: bool = False):
+                   want_row_sums: bool = False, sums_out: Optional[Tensor] = None):
     """returns d_a_new = d_a + W_inᵀ (*) dg;  d_u0 += W_condᵀ·dg  — one launch (csrc/wn_fused.hip).
-    ``want_row_sums``: returns (d_a_new, Σ_{b,t} d_a_new[:, row, :]) — the residual half of the next res_skip bias gradient."""
+    ``want_row_sums``: returns (d_a_new, Σ_{b,t} d_a_new[:, row, :]) — the residual half of the next res_skip bias gradient
+    (reduced into ``sums_out`` [n] when given)."""
     lib = _lib.load()
     B, _, L = dg.shape
     part = torch.empty(128, B * ((L + WN_DGRAD_TILE - 1) // WN_DGRAD_TILE), device=dg.device, dtype=torch.float32) if want_row_sums else None
@@ -797,7 +798,11 @@ def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor,
     if t0 is not None:
         KERNEL_TIMER.end("wn_layer_dgrad_kernel", t0, 2.0 * B * L * 2 * n * (3 * n + h),
                          4.0 * B * L * (2 * n + (n if d_a is not None else 0) + n + 2 * h))
-    return (d_a_new, part.sum(dim=1)[:n]) if want_row_sums else d_a_new
+    if not want_row_sums:
+        return d_a_new
+    if sums_out is not None:
+        return d_a_new, torch.sum(part[:n], dim=1, out=sums_out)
+    return d_a_new, part.sum(dim=1)[:n]
 
 
 class WNFn(torch.autograd.Function):
@@ -889,6 +894,12 @@ class WNFn(torch.autograd.Function):
         d_cond_w = torch.zeros_like(cond_w) if need_w else None
         d_cond_b = None
         d_a_sum: Optional[Tensor] = None      # Σ_{b,t} of the current d_a rows when the fused dgrad kernel left it behind
+        # res_skip bias gradients of layers 0..nl-2 = [Σ d_a ; Σ d_out]: the second half is the same for every layer (one
+        # broadcast), the first is reduced straight into its row by the data-gradient launch of the layer above
+        d_rs_b_all = None
+        if need_w and nl > 1:
+            d_rs_b_all = torch.empty(nl - 1, 2 * n, device=dev, dtype=torch.float32)
+            d_rs_b_all[:, n:] = d_out_sum
         for i in reversed(range(nl)):
             last = i == nl - 1
             # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
@@ -917,7 +928,10 @@ class WNFn(torch.autograd.Function):
                     d_rs_b[i] = d_out_sum
                 else:
                     d_rs_w[i], _ = S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul)
-                    d_rs_b[i] = torch.cat([d_a_sum if d_a_sum is not None else row_sum(d_a), d_out_sum])
+                    if d_a_sum is not None and d_rs_b_all is not None:                    # already reduced into row i of the stack
+                        d_rs_b[i] = d_rs_b_all[i]
+                    else:
+                        d_rs_b[i] = torch.cat([d_a_sum if d_a_sum is not None else row_sum(d_a), d_out_sum])
             # ---- through the gate
             dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
             dg_sum = None
@@ -935,7 +949,8 @@ class WNFn(torch.autograd.Function):
             if ctx.fused and h <= 32 and os.environ.get("FST_WN_DGRAD", "fused") == "fused":
                 img_d = wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h)
                 if need_w:
-                    d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i, want_row_sums=True)
+                    d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i, want_row_sums=True,
+                                                  sums_out=d_rs_b_all[i - 1, :n] if i >= 1 and d_rs_b_all is not None else None)
                 else:
                     d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i), None
             else:
