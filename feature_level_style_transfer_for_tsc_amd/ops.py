@@ -979,6 +979,7 @@ class CouplingFn(torch.autograd.Function):
         check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, _same_numel(u, o, xn), ptr(part), stream_ptr()),
               "fst_coupling_fwd")
         ctx.save_for_backward(u, o)
+        ctx.set_materialize_grads(False)      # an unused output's cotangent stays None (no [B, C, L] zero tensor to fill and read)
         return xn, part.sum(dim=0)
 
     @staticmethod
