@@ -6,6 +6,7 @@ device memory and the autograd graph only.  No op has a CPU implementation.
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -506,9 +507,11 @@ class ConvSpec:
         return out
 
     def grad_w(self, x0: Tensor, x1: Optional[Tensor], dy: Tensor, dy2: Optional[Tensor] = None,
-               msplit: Optional[int] = None, x0_mul_off: int = 0, out1: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
+               msplit: Optional[int] = None, x0_mul_off: int = 0, out1: Optional[Tensor] = None,
+               out0: Optional[Tensor] = None) -> Tuple[Tensor, Optional[Tensor]]:
         """``x0_mul_off``: the x operand is x0[i]·x0[i + x0_mul_off] (x0 = a row slice of the saved gate halves).
-        ``out1``: a contiguous [M, C1, 1] tensor (e.g. a row slice of a stacked gradient) that receives dw1 in place."""
+        ``out0`` / ``out1``: contiguous [M, C0, ntaps] / [M, C1, 1] tensors (segments of a flat gradient, zero-filled when
+        the plan does not write every element) that receive the gradients in place."""
         B, L = x0.size(0), x0.size(2)
         plan = self.wg_plan()
         n_wg = max(1, len(plan.items()) // 4)
@@ -516,7 +519,11 @@ class ConvSpec:
                         wgrad_ksplit(B, L, n_wg), x0_mul_off)
         # a dense plan (every tap of every row) makes unpack write every element: no zero fill needed
         alloc = torch.empty if (self.dense_dw or self.row_live is None) else torch.zeros
-        dw0 = alloc(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
+        if out0 is not None:
+            assert out0.shape == (self.M, self.C0, self.ntaps) and out0.is_contiguous() and out0.dtype == torch.float32
+            dw0 = out0
+        else:
+            dw0 = alloc(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
         dw1 = None
         if self.C1:
             if out1 is not None:
@@ -674,6 +681,26 @@ class WNSpecs:
         # dacts = W_rsᵀ·[d_a ; d_out]: rows n, K = 2n channels from two tensors
         self.rs_T = build_plan(n, [Segment(0, n, 0, 1), Segment(1, n, 0, 1)], 1, 1, 0, chunk_c=PIPE_C)
         self.rs_T_last = build_plan(n, [Segment(0, n, 0, 1)], 1, 1, 0, chunk_c=PIPE_C)
+        # The effective weights travel as ONE flat tensor (WNFn's third argument): start_w, start_b, cond_w, cond_b, end_w,
+        # end_b, in_w[0..], in_b[0..], rs_w[0..], rs_b[0..].  The three applications of a WN in a train step (two forward
+        # flows and infer) then hand autograd three flat gradients to sum — two adds per WN instead of two per tensor
+        # (228 tiny launches per step) — and the backward writes every gradient straight into its segment.
+        nl = n_layers
+        self.shapes = ([(n, h, 1), (n,), (2 * n * nl, h, 1), (2 * n * nl,), (2 * h, n, 1), (2 * h,)]
+                       + [(2 * n, n, kernel)] * nl + [(2 * n,)] * nl
+                       + [(2 * n if i < nl - 1 else n, n, 1) for i in range(nl)] + [(2 * n if i < nl - 1 else n,) for i in range(nl)])
+        self.offsets = [0]
+        for sh in self.shapes:
+            self.offsets.append(self.offsets[-1] + int(math.prod(sh)))
+        self.flat_numel = self.offsets[-1]
+
+    def flatten(self, weights: Sequence[Tensor]) -> Tensor:
+        assert len(weights) == len(self.shapes) and all(tuple(w.shape) == sh for w, sh in zip(weights, self.shapes))
+        return torch.cat([w.reshape(-1) for w in weights])
+
+    def unflatten(self, flat: Tensor) -> List[Tensor]:
+        assert flat.numel() == self.flat_numel and flat.is_contiguous()
+        return [flat[self.offsets[i]: self.offsets[i + 1]].view(sh) for i, sh in enumerate(self.shapes)]
 
 
 def wn_fused_ok(n: int, h: int, L: int, *tensors: Tensor) -> bool:
@@ -740,7 +767,7 @@ def wn_pack_bwd(rs_w: Tensor, n: int, last: bool) -> Tensor:
 
 
 def wn_layer_bwd(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, img: Tensor, dg: Tensor, last: bool, n: int,
-                 want_row_sums: bool = False) -> Optional[Tensor]:
+                 want_row_sums: bool = False, sums_out: Optional[Tensor] = None) -> Optional[Tensor]:
     """``want_row_sums``: also returns Σ_{b,t} dg[:, row, :] ([2n]) — the in_layer / cond_layer bias gradient — from per-workgroup
     partials the kernel leaves behind (no extra pass over dg)."""
     lib = _lib.load()
@@ -756,7 +783,11 @@ def wn_layer_bwd(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, img: Tensor, 
     if t0 is not None:
         k = n if last else 2 * n
         KERNEL_TIMER.end("wn_layer_bwd_kernel", t0, 2.0 * B * L * n * k, 4.0 * B * L * (k + 4 * n))
-    return None if part is None else part.sum(dim=1)[: 2 * n]
+    if part is None:
+        return None
+    if sums_out is not None:
+        return torch.sum(part[: 2 * n], dim=1, out=sums_out)
+    return part.sum(dim=1)[: 2 * n]
 
 
 def wn_pack_dgrad(in_w: Tensor, cond_w: Tensor, n: int, h: int) -> Tensor:
@@ -812,14 +843,16 @@ class WNFn(torch.autograd.Function):
     the cond_layer 1x1 is folded into each in_layer GEMM as 25 extra K rows, so the [B, 2n·8, L]
     conditioning tensor of the reference (1 GB at B=256, L=512) is never materialised.
     ``u0`` may be a channel-slice view of a wider tensor (explicit batch stride).
-    Argument order after (specs, u0): start_w, start_b, cond_w, cond_b, end_w, end_b,
-    in_w[0..], in_b[0..], rs_w[0..], rs_b[0..]  — effective (weight-norm-folded) weights.
+    ``flat``: the effective (weight-norm-folded) weights as one tensor in ``WNSpecs.shapes`` order — start_w, start_b,
+    cond_w, cond_b, end_w, end_b, in_w[0..], in_b[0..], rs_w[0..], rs_b[0..] (``WNSpecs.flatten``).
     """
 
     @staticmethod
-    def forward(ctx, specs: WNSpecs, u0: Tensor, *weights: Tensor):
+    def forward(ctx, specs: WNSpecs, u0: Tensor, flat: Tensor):
         lib = _lib.load()
         S, nl = specs, specs.n_layers
+        flat = flat.contiguous()
+        weights = S.unflatten(flat)
         start_w, start_b, cond_w, cond_b, end_w, end_b = weights[:6]
         in_w, in_b = weights[6: 6 + nl], weights[6 + nl: 6 + 2 * nl]
         rs_w, rs_b = weights[6 + 2 * nl: 6 + 3 * nl], weights[6 + 3 * nl: 6 + 4 * nl]
@@ -864,7 +897,7 @@ class WNFn(torch.autograd.Function):
         ctx.fused = fused
         if fused:
             acts_list = ts_list                                           # placeholders (same count) for the saved-tensor layout
-        ctx.save_for_backward(u0, out, *a_list, *ts_list, *acts_list, start_w, cond_w, end_w, *in_w, *rs_w)
+        ctx.save_for_backward(u0, out, *a_list, *ts_list, *acts_list, flat)
         return o
 
     @staticmethod
@@ -875,30 +908,38 @@ class WNFn(torch.autograd.Function):
         sv = ctx.saved_tensors
         u0, out = sv[0], sv[1]
         a_list, ts_list, acts_list = sv[2: 2 + nl], sv[2 + nl: 2 + 2 * nl], sv[2 + 2 * nl: 2 + 3 * nl]
-        start_w, cond_w, end_w = sv[2 + 3 * nl: 5 + 3 * nl]
-        in_w, rs_w = sv[5 + 3 * nl: 5 + 4 * nl], sv[5 + 4 * nl: 5 + 5 * nl]
-        need_w = any(ctx.needs_input_grad[2:]) and _want_weight_grad()
+        flat = sv[2 + 3 * nl]
+        weights = S.unflatten(flat)
+        start_w, cond_w, end_w = weights[0], weights[2], weights[4]
+        in_w, rs_w = weights[6: 6 + nl], weights[6 + 2 * nl: 6 + 3 * nl]
+        need_w = ctx.needs_input_grad[2] and _want_weight_grad()
+        # every gradient is written into its segment of one flat tensor (zero-filled once: atomically accumulated row sums
+        # and plans that skip dead taps rely on it)
+        d_flat = torch.zeros_like(flat) if need_w else None
+        dw = S.unflatten(d_flat) if need_w else [None] * len(S.shapes)
+        g_start_w, g_start_b, g_cond_w, g_cond_b, g_end_w, g_end_b = dw[:6]
+        g_in_w, g_in_b = dw[6: 6 + nl], dw[6 + nl: 6 + 2 * nl]
+        g_rs_w, g_rs_b = dw[6 + 2 * nl: 6 + 3 * nl], dw[6 + 3 * nl: 6 + 4 * nl]
         do = do.contiguous()
         B, _, L = u0.shape
         dev = u0.device
 
         d_out = S.end.grad_x0(do, end_w)
-        d_end_w = d_end_b = None
         if need_w:
-            d_end_w, _ = S.end.grad_w(out, None, do)
-            d_end_b = row_sum(do)
-        d_out_sum = row_sum(d_out) if need_w else None
+            S.end.grad_w(out, None, do, out0=g_end_w)
+            row_sum(do, out=g_end_b)
+        # Σ_{b,t} d_out: the res_skip bias gradient of the last layer, and the skip half of every other layer's
+        d_out_sum = row_sum(d_out, out=g_rs_b[nl - 1]) if need_w else None
         d_u0 = torch.zeros(B, h, L, device=dev, dtype=torch.float32)
         d_a: Optional[Tensor] = None
-        d_in_w, d_in_b, d_rs_w, d_rs_b = [None] * nl, [None] * nl, [None] * nl, [None] * nl
-        d_cond_w = torch.zeros_like(cond_w) if need_w else None
-        d_cond_b = None
         d_a_sum: Optional[Tensor] = None      # Σ_{b,t} of the current d_a rows when the fused dgrad kernel left it behind
-        # res_skip bias gradients of layers 0..nl-2 = [Σ d_a ; Σ d_out]: the second half is the same for every layer (one
-        # broadcast), the first is reduced straight into its row by the data-gradient launch of the layer above
+        # res_skip bias gradients of layers 0..nl-2 = [Σ d_a ; Σ d_out] are consecutive segments: one [nl-1, 2n] view whose
+        # second half is the same for every layer (one broadcast) and whose first half is reduced straight into its row by
+        # the data-gradient launch of the layer above
         d_rs_b_all = None
         if need_w and nl > 1:
-            d_rs_b_all = torch.empty(nl - 1, 2 * n, device=dev, dtype=torch.float32)
+            o0 = S.offsets[6 + 3 * nl]
+            d_rs_b_all = d_flat[o0: o0 + (nl - 1) * 2 * n].view(nl - 1, 2 * n)
             d_rs_b_all[:, n:] = d_out_sum
         for i in reversed(range(nl)):
             last = i == nl - 1
@@ -924,45 +965,44 @@ class WNFn(torch.autograd.Function):
                 if ctx.fused and os.environ.get("FST_WN_PROD", "1") == "0":                   # diagnostics: materialise acts
                     x_rs, mul = (ts_list[i][:, :n] * ts_list[i][:, n:]).contiguous(), 0
                 if last:
-                    d_rs_w[i], _ = S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul)
-                    d_rs_b[i] = d_out_sum
+                    S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul, out0=g_rs_w[i])      # (its bias gradient is d_out_sum, in place)
                 else:
-                    d_rs_w[i], _ = S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul)
-                    if d_a_sum is not None and d_rs_b_all is not None:                    # already reduced into row i of the stack
-                        d_rs_b[i] = d_rs_b_all[i]
-                    else:
-                        d_rs_b[i] = torch.cat([d_a_sum if d_a_sum is not None else row_sum(d_a), d_out_sum])
+                    S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul, out0=g_rs_w[i])
+                    if d_a_sum is None:                   # not left behind by a fused data-gradient launch: one pass over d_a
+                        row_sum(d_a, out=d_rs_b_all[i, :n])
             # ---- through the gate
             dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
             dg_sum = None
             if fused_bwd:
                 dg_sum = wn_layer_bwd(None if last else d_a, d_out, ts_list[i], wn_pack_bwd(rs_w[i], n, last), dg, last, n,
-                                      want_row_sums=need_w)
+                                      want_row_sums=need_w, sums_out=g_in_b[i])
             else:
                 check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]),
                                        stream_ptr()), "fst_gate_bwd")
             if need_w:
-                # the layer's rows of the stacked cond_layer gradient are written in place by the unpack
-                d_in_w[i], _ = S.ins[i].grad_w(a_list[i], u0, dg, out1=d_cond_w[2 * n * i: 2 * n * (i + 1)])
-                d_in_b[i] = dg_sum if dg_sum is not None else row_sum(dg)      # fused: reduced inside the backward kernel
+                # in_layer weights and the layer's rows of the stacked cond_layer weights, unpacked in place
+                S.ins[i].grad_w(a_list[i], u0, dg, out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])
+                if dg_sum is None:                        # fused: reduced inside the backward kernel, straight into the segment
+                    row_sum(dg, out=g_in_b[i])
             # ---- into the layer input (residual path + dilated conv) and into the conditioning input
             if ctx.fused and h <= 32 and os.environ.get("FST_WN_DGRAD", "fused") == "fused":
                 img_d = wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h)
                 if need_w:
                     d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i, want_row_sums=True,
-                                                  sums_out=d_rs_b_all[i - 1, :n] if i >= 1 and d_rs_b_all is not None else None)
+                                                  sums_out=d_rs_b_all[i - 1, :n] if i >= 1 else g_start_b)
                 else:
                     d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i), None
             else:
                 d_a, d_a_sum = S.ins[i].grad_x01(dg, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], d_a, d_u0), None
         S.start.grad_x0(d_a, start_w, out=d_u0, flags=EPI_ACC1)
-        d_start_w = d_start_b = None
         if need_w:
-            d_start_w, _ = S.start.grad_w(u0, None, d_a)
-            d_start_b = d_a_sum if d_a_sum is not None else row_sum(d_a)
-            d_cond_b = torch.cat(d_in_b)                                       # cond_layer bias = the in_layer biases, stacked
-        grads = [d_start_w, d_start_b, d_cond_w, d_cond_b, d_end_w, d_end_b, *d_in_w, *d_in_b, *d_rs_w, *d_rs_b]
-        return (None, d_u0 if ctx.needs_input_grad[1] else None, *grads)
+            S.start.grad_w(u0, None, d_a, out0=g_start_w)
+            if d_a_sum is None:
+                row_sum(d_a, out=g_start_b)
+            # cond_layer bias = the in_layer biases, stacked (consecutive segments: one copy)
+            o0 = S.offsets[6 + nl]
+            g_cond_b.copy_(d_flat[o0: o0 + nl * 2 * n])
+        return None, (d_u0 if ctx.needs_input_grad[1] else None), d_flat
 
 
 class CouplingFn(torch.autograd.Function):

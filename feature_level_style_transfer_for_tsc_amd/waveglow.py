@@ -70,15 +70,16 @@ class WN(nn.Module):
         self.specs = ops.WNSpecs(n_in_channels, n_channels, n_layers, kernel_size)
         self._fold_cache = None
 
-    def folded_weights(self) -> List[torch.Tensor]:
-        """Effective weights g·v/‖v‖.  Inside ``WaveGlow.shared_fold()`` (one train step: the weights are the same
-        for the two forward passes and ``infer``) the fold is done once and its autograd graph is shared."""
-        if self._fold_cache is not None and self._fold_cache[0]:
+    def folded_weights(self) -> torch.Tensor:
+        """Effective weights g·v/‖v‖ as ONE flat tensor in ``WNSpecs.shapes`` order.  Inside ``WaveGlow.shared_fold()`` (one
+        train step: the weights are the same for the two forward passes and ``infer``) the fold is done once and its
+        autograd graph is shared: the three applications' gradients are summed on the flat tensor (two adds per WN)."""
+        if self._fold_cache is not None and self._fold_cache[0] is not None:
             return self._fold_cache[0]
-        w = self._fold()
+        flat = self.specs.flatten(self._fold())
         if self._fold_cache is not None:
-            self._fold_cache[0] = w
-        return w
+            self._fold_cache[0] = flat
+        return flat
 
     def _fold(self) -> List[torch.Tensor]:
         w = [_folded(self.start), self.start.bias, _folded(self.cond_layer), self.cond_layer.bias,
@@ -88,7 +89,7 @@ class WN(nn.Module):
         return w
 
     def forward(self, forward_input: torch.Tensor) -> torch.Tensor:
-        return ops.WNFn.apply(self.specs, forward_input, *self.folded_weights())
+        return ops.WNFn.apply(self.specs, forward_input, self.folded_weights())
 
 
 class WaveGlow(nn.Module):

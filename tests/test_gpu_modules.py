@@ -526,5 +526,6 @@ def test_trainer_state_checkpoint_resume_equals_uninterrupted(tmp_path):
     got_params = fresh._state_tensors()
     for k in ("m.nf.WN.0.in_layers.3.weight_v", "m.clf_t.hidden.weight", "m.ad_net.ad_layer1.weight", "m.cpc.Wk.0.weight",
               "m.noise.apply_learnable_weight.weight"):
-        close(got_params[k], want_params[k], 2e-3, "post-step " + k)        # (ad_net: clamped to +-5e-4, rounding-level differences show)
+        # ad_net's weights are clamped to +-5e-4: its scale is tiny and run-to-run rounding (fp32 atomics) shows at 1e-6 absolute
+        close(got_params[k], want_params[k], 1e-2 if ".ad_net." in k else 2e-3, "post-step " + k)
     assert fresh.m["noise"].time == tr.m["noise"].time and fresh.m["ad_net"].iter_num == tr.m["ad_net"].iter_num
