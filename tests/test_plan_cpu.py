@@ -131,3 +131,24 @@ def test_item_table_groups_share_an_m_group():
                for q, e in enumerate(ent[g]) if e[1] > e[0])
     assert covered == want
     assert plan.table[8] == len(items) and plan.table[9] == WG_ITEMS and plan.length == plan.table.size
+
+
+@pytest.mark.parametrize("h,n,nl", [(25, 120, 8), (3, 8, 2), (4, 16, 1)])
+def test_wn_flat_weight_layout(h, n, nl):
+    """WNSpecs.flatten / unflatten: the order and shapes WNFn documents, a lossless round trip of a real WN's folded
+    weights, and the two adjacencies its backward relies on — the in_layer biases form one [nl·2n] run (copied into the
+    cond_layer bias gradient) and the res_skip biases of layers 0..nl-2 one [nl-1, 2n] block."""
+    import feature_level_style_transfer_for_tsc_amd as fst
+    torch.manual_seed(n)
+    wn = fst.WN(h, nl, n, 3)
+    S = wn.specs
+    ws = [w.detach() for w in wn._fold()]
+    assert [tuple(w.shape) for w in ws] == list(S.shapes) and len(S.shapes) == 6 + 4 * nl
+    flat = S.flatten(ws)
+    assert flat.numel() == S.flat_numel == sum(w.numel() for w in ws)
+    back = S.unflatten(flat)
+    assert all(torch.equal(a, b) and a.data_ptr() == flat.data_ptr() + 4 * S.offsets[i] for i, (a, b) in enumerate(zip(back, ws)))
+    in_b0, rs_b0 = 6 + nl, 6 + 3 * nl
+    assert all(S.offsets[in_b0 + i + 1] - S.offsets[in_b0 + i] == 2 * n for i in range(nl))
+    assert S.shapes[3] == (2 * n * nl,) and S.offsets[in_b0 + nl] - S.offsets[in_b0] == 2 * n * nl
+    assert all(S.shapes[rs_b0 + i] == (2 * n,) for i in range(nl - 1)) and S.shapes[rs_b0 + nl - 1] == (n,)
