@@ -271,20 +271,6 @@ __device__ __forceinline__ void wn_fetch_tile(float4 (&q)[4], const float* src_r
     if (t_ok && row < rows_valid) q[j] = *reinterpret_cast<const float4*>(src_rows + (long long)row * L + t + c4);
   }
 }
-// The same four pieces as loads that ALWAYS issue (lanes outside the tile read a 16-byte block of zeros instead of being
-// masked off): a caller that counts its outstanding memory operations for s_waitcnt vmcnt(N) needs the number of loads in
-// flight to be a constant, not a function of which lanes are inside the tensor.
-__device__ __forceinline__ void wn_fetch_tile_counted(float4 (&q)[4], const float* src_rows, int rows_valid, int L, int t, int lane,
-                                                      const char* zero16) {
-  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
-  const bool t_ok = t + c4 < L;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = rrow + 8 * j;
-    const float* src = (t_ok && row < rows_valid) ? src_rows + (long long)row * L + t + c4 : reinterpret_cast<const float*>(zero16);
-    q[j] = *reinterpret_cast<const float4*>(src);
-  }
-}
 // Accumulator layout ↔ global memory directly (lane = time sample, register r = row (r&3) + 8(r>>2) + 4·half): one
 // wave-instruction moves two rows × 32 consecutive samples (two full 128-byte segments).  Sixteen dword accesses per tile
 // instead of four 16-byte ones, but no LDS transpose and — for the loads — no wait inside an epilogue: operand tiles are
@@ -331,25 +317,6 @@ __device__ __forceinline__ void wn_tile_to_acc(float (&v)[16], const float4 (&q)
   for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(tile + (rrow + 8 * j) * 36 + c4) = q[j];
 #pragma unroll
   for (int r = 0; r < 16; ++r) v[r] = tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31];
-}
-
-// accumulator tile + an operand tile fetched earlier (wn_fetch_tile) → dst.  Keeping the operand loads of tile i+1 in
-// flight while tile i is stored matters: vmcnt retires in issue order, so a load issued AFTER a store cannot be waited
-// for without waiting for that store's completion too (one HBM write latency per tile, serialised).
-__device__ __forceinline__ void wn_store_tile_add(const float (&v)[16], const float4 (&e)[4], float* tile, float* dst_rows,
-                                                  int rows_valid, int L, int t, int lane) {
-  const int half = lane >> 5, l31 = lane & 31;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = v[r];
-  const int rrow = lane >> 3, c4 = (lane & 7) * 4;
-  const bool t_ok = t + c4 < L;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = rrow + 8 * j;
-    float4 w = *reinterpret_cast<const float4*>(tile + row * 36 + c4);
-    w.x += e[j].x; w.y += e[j].y; w.z += e[j].z; w.w += e[j].w;
-    if (t_ok && row < rows_valid) *reinterpret_cast<float4*>(dst_rows + (long long)row * L + t + c4) = w;
-  }
 }
 
 // Row sums of an accumulator tile on its way out (bias gradients: Σ_{b,t} of every row): after the transpose each lane
