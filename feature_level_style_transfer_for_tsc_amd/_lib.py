@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
@@ -55,14 +55,15 @@ _SIGNATURES = {
     "fst_coupling_inv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_coupling_inv_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_image_bytes": (c_int64, [c_int, c_int]),
-    "fst_wn_pack": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int64, c_void_p]),
+    "fst_wn_pack": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, c_void_p]),
     "fst_wn_layer_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int64, c_void_p]),
     "fst_wn_bwd_image_bytes": (c_int64, [c_int, c_int]),
     "fst_wn_pack_bwd": (c_int, [_P, c_int, c_int, _P, c_int64, c_void_p]),
     "fst_wn_layer_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_dgrad_image_bytes": (c_int64, [c_int]),
-    "fst_wn_pack_dgrad": (c_int, [_P, _P, c_int, c_int, _P, c_int64, c_void_p]),
+    "fst_wn_pack_dgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int64, c_void_p]),
+    "fst_wn_dgrad_fits": (c_int, [c_int, c_int, c_int]),
     "fst_wn_layer_dgrad": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
                                    c_void_p]),
     "fst_gru_fwd": (c_int, [_P, _P, _P, _P, _P, _I32P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),

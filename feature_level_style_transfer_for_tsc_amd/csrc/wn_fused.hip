@@ -161,9 +161,10 @@ extern "C" int64_t fst_wn_image_bytes(int n, int h) {
 }
 
 extern "C" int fst_wn_pack(const float* in_w, const float* cond_w, const float* in_b, const float* cond_b,
-                           const float* rs_w, const float* rs_b, int n, int h, int last, void* image,
+                           const float* rs_w, const float* rs_b, int n, int h, int ntaps, int last, void* image,
                            int64_t image_bytes, void* stream) {
   FST_REQUIRE(in_w && cond_w && in_b && cond_b && rs_w && rs_b && image, "fst_wn_pack: null operand");
+  FST_REQUIRE(ntaps == 3, "fst_wn_pack: the fused WN kernels are 3-tap (in_w [2n][n][3]); got %d taps", ntaps);
   FST_REQUIRE(n > 0 && n < 128 && h > 0, "fst_wn_pack: needs 0 < n < 128 (one spare K row carries the bias), h > 0; n=%d h=%d", n, h);
   FST_REQUIRE(image_bytes == fst_wn_image_bytes(n, h), "fst_wn_pack: image is %lld bytes, expected %lld",
               (long long)image_bytes, (long long)fst_wn_image_bytes(n, h));
@@ -934,9 +935,10 @@ extern "C" int64_t fst_wn_dgrad_image_bytes(int n) {
   return (int64_t)((2 * n + 15) / 16) * DG_A_BYTES + 16;
 }
 
-extern "C" int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, void* image, int64_t image_bytes,
+extern "C" int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, int ntaps, void* image, int64_t image_bytes,
                                  void* stream) {
   FST_REQUIRE(in_w && cond_w && image && n > 0 && n <= 128 && h > 0 && h <= 32, "fst_wn_pack_dgrad: needs n <= 128, h <= 32 (n=%d h=%d)", n, h);
+  FST_REQUIRE(ntaps == 3, "fst_wn_pack_dgrad: the fused WN kernels are 3-tap (in_w [2n][n][3]); got %d taps", ntaps);
   FST_REQUIRE(image_bytes == fst_wn_dgrad_image_bytes(n), "fst_wn_pack_dgrad: image is %lld bytes, expected %lld",
               (long long)image_bytes, (long long)fst_wn_dgrad_image_bytes(n));
   FST_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, "fst_wn_pack_dgrad: image must be 16-byte aligned");
@@ -1125,6 +1127,26 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
   }
 }
 
+// window geometry of one fst_wn_layer_dgrad stage at dilation dil: (32-sample blocks per window, bytes per window, bytes per ring slot)
+static inline void wn_dgrad_geometry(int dil, int* nblkw, int* gsw, int* slot) {
+  *nblkw = (DG_TN + 2 * dil + 3 + 31) / 32;
+  *gsw = *nblkw * 1024 + 128;
+  *slot = DG_A_BYTES + 2 * *gsw;
+}
+
+// 1 when fst_wn_layer_dgrad serves (n, h, dil): two ring slots fit the 160 KiB of LDS and the counted-wait table covers a stage
+// (with 512-sample tiles: up to dilation 128, i.e. WN stacks of up to 8 layers); the host side falls back to the generic
+// data-gradient launch otherwise.
+extern "C" int fst_wn_dgrad_fits(int n, int h, int dil) {
+  if (!(n > 0 && n <= 128 && h > 0 && h <= 32 && dil > 0)) return 0;
+  int nblkw, gsw, slot;
+  wn_dgrad_geometry(dil, &nblkw, &gsw, &slot);
+  if (2 * slot > 160 * 1024) return 0;
+  const int ns = 3 * slot <= 160 * 1024 ? 3 : 2;
+  const int NI = DG_A_BLOCKS * 2 + 2 * nblkw;
+  return ((NI + 7) / 8) * (ns - 2) <= 16 ? 1 : 0;
+}
+
 extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new,
                                   float* d_u0, float* row_sums, int64_t row_sums_rows, int B, int L, int n, int h, int dil,
                                   int64_t numel_a, int64_t numel_u0, void* stream) {
@@ -1146,9 +1168,7 @@ extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t im
   p.n_wg = B * p.tiles_per_seq;
   FST_REQUIRE(row_sums == nullptr || row_sums_rows == p.n_wg, "fst_wn_layer_dgrad: row_sums has %lld rows, the launch has %d "
               "workgroups (B x ceil(L/512))", (long long)row_sums_rows, p.n_wg);
-  p.nblkw = (DG_TN + 2 * dil + 3 + 31) / 32;
-  p.gsw = p.nblkw * 1024 + 128;
-  p.slot = DG_A_BYTES + 2 * p.gsw;
+  wn_dgrad_geometry(dil, &p.nblkw, &p.gsw, &p.slot);
   p.ns = 3 * p.slot <= 160 * 1024 ? 3 : 2;
   FST_REQUIRE(2 * p.slot <= 160 * 1024, "fst_wn_layer_dgrad: dilation %d needs a %d-byte window slot: too large for LDS", dil, p.slot);
   const int NI = DG_A_BLOCKS * 2 + 2 * p.nblkw;

@@ -703,10 +703,12 @@ class WNSpecs:
         return [flat[self.offsets[i]: self.offsets[i + 1]].view(sh) for i, sh in enumerate(self.shapes)]
 
 
-def wn_fused_ok(n: int, h: int, L: int, *tensors: Tensor) -> bool:
+def wn_fused_ok(n: int, h: int, L: int, *tensors: Tensor, kernel: int = 3) -> bool:
     """Whether a WN layer takes the fused one-launch-per-layer kernels (csrc/wn_fused.hip): split-bf16 arithmetic,
-    n < 128 (one spare K row carries the biases), 16-byte aligned rows."""
-    if MATH != "bf16x3" or not (0 < n < 128) or L % 4 != 0 or os.environ.get("FST_WN_FUSED", "1") == "0":
+    three taps (the kernels hard-code taps at 0 and ±dil; the reference's WN takes any kernel_size,
+    Simplified_NF_WaveGlow.py:60 — other sizes run on the generic conv engine), n < 128 (one spare K row carries the
+    biases), 16-byte aligned rows."""
+    if MATH != "bf16x3" or kernel != 3 or not (0 < n < 128) or L % 4 != 0 or os.environ.get("FST_WN_FUSED", "1") == "0":
         return False
     return all(t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0 for t in tensors)
 
@@ -715,6 +717,8 @@ def wn_pack_layer(in_w: Tensor, cond_w: Tensor, in_b: Tensor, cond_b: Tensor, rs
                   last: bool) -> Tensor:
     """One layer's weight image for the fused kernels (cached for the step like every packed weight)."""
     lib = _lib.load()
+    if in_w.dim() != 3 or in_w.size(0) != 2 * n or in_w.size(1) != n:
+        raise ValueError(f"wn_pack_layer: in_w must be [2n, n, taps], got {tuple(in_w.shape)} for n={n}")
     key = None
     if _PACK_CACHE is not None:
         key = ("wn", n, h, last) + tuple((t.data_ptr(), t._version) for t in (in_w, cond_w, in_b, cond_b, rs_w, rs_b))
@@ -724,7 +728,7 @@ def wn_pack_layer(in_w: Tensor, cond_w: Tensor, in_b: Tensor, cond_b: Tensor, rs
     nbytes = lib.fst_wn_image_bytes(n, h)
     img = torch.empty(nbytes // 4, device=in_w.device, dtype=torch.float32)
     src = [t.contiguous() for t in (in_w, cond_w, in_b, cond_b, rs_w, rs_b)]
-    check(lib.fst_wn_pack(*[ptr(t) for t in src], n, h, int(last), ptr(img), nbytes, stream_ptr()), "fst_wn_pack")
+    check(lib.fst_wn_pack(*[ptr(t) for t in src], n, h, in_w.size(2), int(last), ptr(img), nbytes, stream_ptr()), "fst_wn_pack")
     if key is not None:
         _PACK_CACHE[key] = (img, in_w, cond_w, in_b, cond_b, rs_w, rs_b, src)
     return img
@@ -801,13 +805,20 @@ def wn_pack_dgrad(in_w: Tensor, cond_w: Tensor, n: int, h: int) -> Tensor:
     nbytes = lib.fst_wn_dgrad_image_bytes(n)
     img = torch.empty(nbytes // 4, device=in_w.device, dtype=torch.float32)
     src = (in_w.contiguous(), cond_w.contiguous())
-    check(lib.fst_wn_pack_dgrad(ptr(src[0]), ptr(src[1]), n, h, ptr(img), nbytes, stream_ptr()), "fst_wn_pack_dgrad")
+    check(lib.fst_wn_pack_dgrad(ptr(src[0]), ptr(src[1]), n, h, in_w.size(2), ptr(img), nbytes, stream_ptr()), "fst_wn_pack_dgrad")
     if key is not None:
         _PACK_CACHE[key] = (img, in_w, cond_w, src)
     return img
 
 
 WN_DGRAD_TILE = 512       # time samples per workgroup of fst_wn_layer_dgrad (the library checks the row-sum extent against it)
+
+
+def wn_dgrad_ok(n: int, h: int, dil: int) -> bool:
+    """Whether fst_wn_layer_dgrad serves this layer: the library's own test (two window slots of 512 + 2·dil samples must fit
+    the LDS: dilations up to 128, i.e. WN stacks of up to 8 layers).  Deeper stacks (the reference's WN takes any n_layers)
+    fall back to the generic data-gradient launch per layer."""
+    return bool(_lib.load().fst_wn_dgrad_fits(n, h, dil))
 
 
 def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor, n: int, h: int, dil: int,
@@ -860,7 +871,7 @@ class WNFn(torch.autograd.Function):
         h, n = S.h, S.n
         a = S.start.forward(u0, None, start_w, None, start_b)
         a_list, ts_list, acts_list = [a], [], []
-        fused = wn_fused_ok(n, h, L, a, u0)
+        fused = wn_fused_ok(n, h, L, a, u0, kernel=S.kernel)
         if fused:
             # one launch per layer: dilated conv + cond rows → gate in registers → res_skip → residual / skip adds
             out = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
@@ -985,7 +996,7 @@ class WNFn(torch.autograd.Function):
                 if dg_sum is None:                        # fused: reduced inside the backward kernel, straight into the segment
                     row_sum(dg, out=g_in_b[i])
             # ---- into the layer input (residual path + dilated conv) and into the conditioning input
-            if ctx.fused and h <= 32 and os.environ.get("FST_WN_DGRAD", "fused") == "fused":
+            if ctx.fused and wn_dgrad_ok(n, h, 2 ** i) and os.environ.get("FST_WN_DGRAD", "fused") == "fused":
                 img_d = wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h)
                 if need_w:
                     d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i, want_row_sums=True,

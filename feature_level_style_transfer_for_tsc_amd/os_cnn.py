@@ -104,22 +104,26 @@ def inference_mode(*bns: nn.BatchNorm1d) -> bool:
 
 
 class _FoldedBN:
-    """conv → eval-mode BatchNorm as ONE conv:  W' = W·γ/√(σ²+ε),  b' = (b − μ)·γ/√(σ²+ε) + β.  Cached on the version
-    counters of the six tensors it is made of, so an eval loop folds once."""
+    """conv → eval-mode BatchNorm as ONE conv:  W' = W·γ/√(σ²+ε),  b' = (b − μ)·γ/√(σ²+ε) + β.
 
-    def __init__(self):
-        self._key, self._wb = None, None
+    The fold lives exactly as long as the enclosing ``ops.pack_cache()`` scope — the eval pass (checkpoint.eval_accuracy)
+    and the K-way voting forward (voting.collect_logits) open one around all their batches, so an eval loop folds once —
+    and is redone on every call outside such a scope.  It is deliberately NOT keyed on tensor version counters: the train
+    step updates parameters and running statistics through raw pointers (fst_bn_finalize) and inside replayed hipGraphs,
+    neither of which bumps a version, so a version-keyed fold would go stale silently after the first eval."""
 
     def get(self, conv: nn.Conv1d, bn: nn.BatchNorm1d):
-        src = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-        key = tuple((t.data_ptr(), t._version) for t in src) + (bn.eps,)
-        if key != self._key:
-            with torch.no_grad():
-                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-                self._wb = ((conv.weight * scale.view(-1, 1, 1)).contiguous(),
-                            ((conv.bias - bn.running_mean) * scale + bn.bias).contiguous())
-            self._key = key
-        return self._wb
+        cache = ops._PACK_CACHE
+        key = ("bn_fold", id(self))
+        if cache is not None and key in cache:
+            return cache[key][0]
+        with torch.no_grad():
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            wb = ((conv.weight * scale.view(-1, 1, 1)).contiguous(),
+                  ((conv.bias - bn.running_mean) * scale + bn.bias).contiguous())
+        if cache is not None:
+            cache[key] = (wb, self)                  # keeps ``self`` alive: the id cannot be recycled within the scope
+        return wb
 
 
 def batch_norm_act(y: torch.Tensor, bn: nn.BatchNorm1d, relu: bool) -> torch.Tensor:

@@ -247,10 +247,18 @@ class JointTrainer:
         cpu = lambda t: t.detach().cpu().clone()
         cpc = self.opt_cpc
         noise = self.m["noise"]
+
+        def opt_cpu(o):
+            # Optimizer.state_dict() aliases the live (device) moment tensors: copy them out, or an in-memory snapshot
+            # followed by more steps would restore advanced moments
+            sd = o.state_dict()
+            return {"state": {i: {n: (cpu(v) if isinstance(v, torch.Tensor) else v) for n, v in st.items()}
+                              for i, st in sd["state"].items()},
+                    "param_groups": [dict(g) for g in sd["param_groups"]]}
         return {
             "modules": {k: {n: cpu(v) for n, v in self.m[k].state_dict().items()} for k in self.MODULES},
-            "opts": {k: o.state_dict() for k, o in self.opts.items()},
-            "opt_w_t": self.opt_w_t.state_dict(), "opt_w_s": self.opt_w_s.state_dict(),
+            "opts": {k: opt_cpu(o) for k, o in self.opts.items()},
+            "opt_w_t": opt_cpu(self.opt_w_t), "opt_w_s": opt_cpu(self.opt_w_s),
             "opt_cpc": {"step": [cpu(g["step"]) for g in cpc.param_groups],
                         "exp_avg": [[cpu(cpc.state[p]["exp_avg"]) for p in g["params"]] for g in cpc.param_groups],
                         "exp_avg_sq": [[cpu(cpc.state[p]["exp_avg_sq"]) for p in g["params"]] for g in cpc.param_groups]},

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 6
+#define FST_ABI_VERSION 7
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -194,7 +194,9 @@ int fst_coupling_inv_bwd(const float* xn, const float* o, const float* dxn,
  * ------------------------------------------------------------------------------------------- */
 int64_t fst_wn_image_bytes(int n, int h);
 int fst_wn_pack(const float* in_w, const float* cond_w, const float* in_b, const float* cond_b,
-                const float* rs_w, const float* rs_b, int n, int h, int last, void* image, int64_t image_bytes, void* stream);
+                const float* rs_w, const float* rs_b, int n, int h, int ntaps /* of in_w; the fused kernels are 3-tap: anything
+                else is refused (Simplified_NF_WaveGlow.py:60 allows any kernel_size; the host side then takes the generic
+                conv-engine path) */, int last, void* image, int64_t image_bytes, void* stream);
 int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, int64_t u0_bs, const void* image, int64_t image_bytes,
                      float* ts, float* acts, float* a_next, float* out, int first, int last,
                      int B, int L, int n, int h, int dil, int64_t numel_a, void* stream);
@@ -217,7 +219,11 @@ int fst_wn_layer_bwd(const float* d_a_next /* NULL iff last */, const float* d_o
  *   d_u0   += W_condᵀ · dg
  * in_w [2n][n][3], cond_w [2n][h] (this layer's rows); dg [B][2n][L]; d_a / d_a_new [B][n][L]; d_u0 [B][h][L] contiguous. */
 int64_t fst_wn_dgrad_image_bytes(int n);
-int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, void* image, int64_t image_bytes, void* stream);
+int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, int ntaps /* must be 3 */, void* image,
+                      int64_t image_bytes, void* stream);
+/* 1 when fst_wn_layer_dgrad serves (n, h, dil) — n <= 128, h <= 32 and two window slots of 512 + 2·dil samples fit the 160 KiB
+ * of LDS (dil <= 128: WN stacks of up to 8 layers) — else 0: the caller then uses fst_conv_gemm's data-gradient plan. */
+int fst_wn_dgrad_fits(int n, int h, int dil);
 int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new, float* d_u0,
                        float* row_sums /* optional [128][B·⌈L/512⌉]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
                        int B, int L, int n, int h, int dil, int64_t numel_a, int64_t numel_u0, void* stream);

@@ -19,7 +19,9 @@ def _worker(rank, world, port, q):
     bucket = GradBucket()
     bucket.all_reduce(params)                                     # params[2] has no grad: skipped
     s = bucket.mean_scalars(torch.tensor([float(rank), 10.0 * rank]))
-    q.put((rank, params[0].grad.clone(), params[1].grad.clone(), params[2].grad, s))
+    # plain numpy over the queue: a tensor travels as a file descriptor the parent must fetch while this process is still
+    # alive (torch.multiprocessing's fd sharing) — a worker that exits first resets the connection
+    q.put((rank, params[0].grad.numpy().copy(), params[1].grad.numpy().copy(), params[2].grad, s.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -35,6 +37,7 @@ def test_grad_bucket_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     for rank, g0, g1, g2, s in out:
+        g0, g1, s = torch.from_numpy(g0), torch.from_numpy(g1), torch.from_numpy(s)
         assert torch.allclose(g0, torch.full((3, 5), 1.5))
         assert torch.allclose(g1, torch.arange(7.0) * 1.5)
         assert g2 is None
@@ -71,7 +74,7 @@ def _worker_global(rank, world, port, q):
         # local loss: mean over local rows of ((x - m)^2).sum() + coupling of local rows with ALL rows
         loss = ((x - m) ** 2).sum(dim=1).mean() + (x @ allx.t()).sum(dim=1).mean() / 4.0
         loss.backward()
-    q.put((rank, m.detach().clone(), allx.detach().clone(), s.clone(), n, float(loss), x.grad.clone()))
+    q.put((rank, m.detach().numpy().copy(), allx.detach().numpy().copy(), s.numpy().copy(), n, float(loss), x.grad.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -93,6 +96,7 @@ def test_global_batch_collectives_match_single_process():
     L.backward()
     losses = []
     for rank, m_r, allx, s, n, loss, gx in out:
+        m_r, allx, s, gx = (torch.from_numpy(v) for v in (m_r, allx, s, gx))
         assert torch.allclose(m_r, m.detach()) and torch.allclose(allx, xg.detach())
         assert n == world and torch.allclose(s, torch.full((2,), float(world)))
         losses.append(loss)

@@ -39,8 +39,11 @@ def _trainer_from(js, L_t, L_s, ncls):
     return tr
 
 
+FLIP_BOUND = 1e-4      # an imposed branch may differ from the oracle's own only where |pre-activation| <= this · max|pre-activation|
+
+
 @contextlib.contextmanager
-def _head_unit_branches(record=None, impose=None):
+def _head_unit_branches(record=None, impose=None, flips=None):
     """The branch every unit of the ReLU / LeakyReLU layers that run as torch ops takes — the MLP heads (2-D: adversarial
     net, feature discriminator) and the dimension unification (3-D, 512 units per (sample, channel) row) — recorded from
     one run, or imposed on another.  Gradients of a piecewise-linear network are comparable only on the same piece: a unit
@@ -48,10 +51,25 @@ def _head_unit_branches(record=None, impose=None):
     unit at B = 3 moves every gradient upstream of it by percent.  The forward VALUE is unaffected (the pre-activation is
     ~0 either way), so the oracle is stepped on the piece the device run was on and then compared tightly.  The ReLUs
     fused into the BatchNorm kernels (the omni-scale convolutions) cannot be recorded and are left alone: one element
-    there is one of B·C·L."""
+    there is one of B·C·L.
+    Imposing is BOUNDED: wherever the imposed branch differs from the one the oracle's own pre-activation selects, that
+    pre-activation must be within FLIP_BOUND of zero relative to the layer's largest — a unit the device got wrong by more
+    than rounding fails here instead of dragging the oracle along.  ``flips`` (a list) receives (layer index, units
+    flipped, largest |x|/max|x| among them) per layer with any."""
     relu0, leaky0, dimunif0 = F.relu, F.leaky_relu, R.dimension_unification
     it = iter(impose) if impose is not None else None
     inside = [0]
+    layer_no = [0]
+
+    def bounded(x, m):
+        layer_no[0] += 1
+        diff = (x.detach() > 0) != m
+        if bool(diff.any()):
+            worst = float(x.detach()[diff].abs().max()) / max(1e-30, float(x.detach().abs().max()))
+            if flips is not None:
+                flips.append((layer_no[0], int(diff.sum()), worst))
+            assert worst <= FLIP_BOUND, (f"layer {layer_no[0]}: {int(diff.sum())} unit(s) take the other branch on the device with "
+                                         f"|x|/max|x| up to {worst:.2e} — not a rounding-level disagreement")
 
     def synced(x):
         return x.dim() == 2 or record is not None or inside[0] > 0     # the device side calls F.relu only in these layers
@@ -64,6 +82,7 @@ def _head_unit_branches(record=None, impose=None):
             return relu0(x, inplace)
         m = next(it)
         assert m.shape == x.shape, (m.shape, x.shape)
+        bounded(x, m)
         return x * m.to(x.dtype)
 
     def leaky(x, negative_slope=0.01, inplace=False):
@@ -74,6 +93,7 @@ def _head_unit_branches(record=None, impose=None):
             return leaky0(x, negative_slope, inplace)
         m = next(it)
         assert m.shape == x.shape, (m.shape, x.shape)
+        bounded(x, m)
         return torch.where(m, x, negative_slope * x)
 
     def dimunif(*a, **k):
@@ -109,8 +129,11 @@ def _step_both(js, tr, batch, ts):
         rep = tr.step(x_t.to(DEV), y_t.to(DEV), x_s.to(DEV), y_s.to(DEV), epoch=0, t_samples=ts)
     tr.on_grads_ready = None
     assert branches, "no head layer went through torch.nn.functional"
-    with _head_unit_branches(impose=branches):
+    flips = []
+    with _head_unit_branches(impose=branches, flips=flips):
         rep_o = js.step(x_t, y_t, x_s, y_s, epoch=0, t_samples=ts)
+    if os.environ.get("FST_GRAD_REPORT"):
+        print(f"[branch report] {sum(int(b.numel()) for b in branches)} synchronised units, flipped (layer, units, |x|/max): {flips}")
     want = {name: {n: p.grad.detach().numpy().copy() for n, p in P.items() if p.requires_grad and p.grad is not None}
             for name, P in js.m.items()}
     return rep_o, want, rep, grads

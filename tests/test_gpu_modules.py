@@ -529,3 +529,86 @@ def test_trainer_state_checkpoint_resume_equals_uninterrupted(tmp_path):
         # ad_net's weights are clamped to +-5e-4: its scale is tiny and run-to-run rounding (fp32 atomics) shows at 1e-6 absolute
         close(got_params[k], want_params[k], 1e-2 if ".ad_net." in k else 2e-3, "post-step " + k)
     assert fresh.m["noise"].time == tr.m["noise"].time and fresh.m["ad_net"].iter_num == tr.m["ad_net"].iter_num
+
+
+def test_folded_inference_follows_graph_replays():
+    """Round-2 advisor finding: the BatchNorm fold must not be cached across calls on tensor version counters — graph
+    replays and fst_bn_finalize move parameters and running statistics without bumping them.  Capture, eval (folded),
+    replay three steps, eval again: the second folded eval must equal the unfolded eval-mode path (autograd on, BatchNorm
+    kernels reading the live running statistics) and must differ from the first."""
+    g = load("joint_small")
+    tr = _joint_trainer(g)
+    args = [torch.tensor(g[f"s0.{k}"], device=DEV) for k in ("x_t", "y_t", "x_s", "y_s")]
+    torch.manual_seed(5)
+    tr.capture(*args, epoch=0)
+    fe, clf = tr.m["fe_t"], tr.m["clf_t"]
+    x = args[0]
+
+    def evals():
+        fe.eval(); clf.eval()
+        with torch.no_grad():
+            folded, _ = clf(fe(x))
+            acc, _ = fst.eval_accuracy(fe, clf, [(x, args[1])])              # the eval pass itself (fold scoped to its pack_cache)
+        unfolded, _ = clf(fe(x))                                              # autograd on: eval-mode BatchNorm kernels
+        fe.train(); clf.train()
+        return folded.clone(), unfolded.detach().clone(), acc
+    f0, u0, _ = evals()
+    close(f0, u0, 2e-5, "folded vs unfolded before the replays")
+    for i in range(3):
+        tr.replay(*args, (1 + i, 4 - i))
+    f1, u1, _ = evals()
+    close(f1, u1, 2e-5, "folded vs unfolded after three graph replays")
+    assert float((u1 - u0).abs().max()) > 1e-4 * float(u0.abs().max()), "the replays did not move the eval logits: the test is vacuous"
+
+
+def test_trainer_state_in_memory_rollback():
+    """state_dict() must not alias live optimiser moments: snapshot, two more steps, load_state_dict(snapshot), one step ==
+    the same step taken right after the snapshot."""
+    g = load("joint_small")
+    tr = _joint_trainer(g)
+    args = [torch.tensor(g[f"s0.{k}"], device=DEV) for k in ("x_t", "y_t", "x_s", "y_s")]
+    tr.step(*args, epoch=0, t_samples=(2, 5))
+    sd = tr.state_dict()
+    assert all(not v.is_cuda for st in sd["opts"]["nf"]["state"].values() for v in st.values() if isinstance(v, torch.Tensor))
+    want = tr.step(*args, epoch=0, t_samples=(3, 4))
+    want_w = tr.m["nf"].WN[0].in_layers[3].weight_v.detach().clone()
+    tr.step(*args, epoch=0, t_samples=(1, 1))
+    tr.load_state_dict(sd)
+    got = tr.step(*args, epoch=0, t_samples=(3, 4))
+    for k in ("nf_t", "ce_t", "sl_t", "cdan", "fd_s"):
+        assert abs(got[k].item() - want[k].item()) <= 2e-5 * max(1.0, abs(want[k].item())), (k, got[k].item(), want[k].item())
+    close(tr.m["nf"].WN[0].in_layers[3].weight_v, want_w, 2e-3, "weight after rollback + step (RMSprop moments restored)")
+
+
+@pytest.mark.parametrize("n_layers,kernel,fused_expected", [(8, 5, False), (9, 3, True), (3, 3, True)])
+def test_wn_other_depths_and_kernel_sizes_vs_oracle(n_layers, kernel, fused_expected, monkeypatch):
+    """The reference's WN takes any n_layers / kernel_size (Simplified_NF_WaveGlow.py:55-99).  kernel_size = 5 must take the
+    generic conv-engine path (the fused kernels are 3-tap); nine layers reach dilation 256, whose data-gradient window does
+    not fit the fused data-gradient kernel's LDS ring: that layer alone falls back.  Output and every gradient vs the oracle."""
+    from feature_level_style_transfer_for_tsc_amd.waveglow import WN
+    h, n, B, L = 6, 16, 3, 640
+    torch.manual_seed(n_layers * 10 + kernel)
+    wn = WN(h, n_layers, n, kernel).to(DEV)
+    wn.end.weight.data.normal_(0, 0.3); wn.end.bias.data.normal_(0, 0.3)
+    assert ops.wn_dgrad_ok(n, h, 128) and not ops.wn_dgrad_ok(n, h, 256)
+    P = {("WN.0." + k): v.detach().cpu().clone().requires_grad_(True) for k, v in wn.state_dict().items()}
+    monkeypatch.setattr(R, "WN_LAYERS", n_layers)
+    monkeypatch.setattr(R, "WN_KERNEL", kernel)
+    u0 = torch.randn(B, h, L)
+    r = torch.randn(B, 2 * h, L)
+    uo = u0.clone().requires_grad_(True)
+    (R.wn_forward(uo, P, "WN.0.") * r).sum().backward()
+    want = R.wn_forward(u0, P, "WN.0.").detach()
+    ud = u0.to(DEV).requires_grad_(True)
+    timer = ops.KernelTimer()
+    ops.KERNEL_TIMER = timer
+    try:
+        out = wn(ud)
+        (out * r.to(DEV)).sum().backward()
+    finally:
+        ops.KERNEL_TIMER = None
+    keys = timer.summary()
+    assert ("wn_layer_fwd_kernel" in keys) == fused_expected, sorted(keys)
+    close(out, want, 1e-4, "WN output")
+    close(ud.grad, uo.grad, 1e-3, "WN d input")
+    check_grads(wn, {k[5:]: v.grad.numpy() for k, v in P.items() if v.grad is not None}, 1e-3, f"WN({n_layers} layers, k={kernel}) ")

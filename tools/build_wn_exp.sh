@@ -10,7 +10,7 @@ for n in "$@"; do
   if [ -n "$DGMODE" ]; then defs="-DDG_EXP=$n"; name=dgexp$n; else defs="-DWN_EXP=$n"; name=wnexp$n; fi
   ( hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-pass-failed $defs -c \
       feature_level_style_transfer_for_tsc_amd/csrc/wn_fused.hip -o build/exp/wn_fused_$name.o &&
-    hipcc --offload-arch=gfx950 -fPIC -shared build/obj/conv_engine.o build/obj/cpc.o build/obj/gru.o build/obj/pointwise.o \
-      build/exp/wn_fused_$name.o -o build/exp/libfst_$name.so ) &
+    hipcc --offload-arch=gfx950 -fPIC -shared $(ls build/obj/*.o | grep -v '/wn_fused\.o$') \
+      build/exp/wn_fused_$name.o -o build/exp/libfst_$name.so ) &      # every object of the library except the one replaced
 done
 wait
