@@ -68,7 +68,6 @@ __device__ __forceinline__ void block_sum2(float& a, float& b) {
               "%s: B*C*L = %d*%d*%d does not match the tensors' element count %lld", who, (int)(B), (int)(C), (int)(L), \
               (long long)(numel))
 
-#define CH_SPLIT 16   // blocks per channel for the (B,L) reductions
 
 // 16-byte path of the per-row kernels (L a multiple of 4, 16-byte aligned bases): a row of L/4 float4 is covered by
 // tpr = min(256, pow2ceil(L/4)) threads and a 256-thread block walks 256/tpr rows at a time, so every lane carries a
@@ -91,106 +90,185 @@ static inline RowVec row_vec(int L) {
   return v;
 }
 
-// ---------------------------------------------------------------- row sums (bias / beta gradients)
-__global__ __launch_bounds__(256) void row_sum_kernel(const float* x, long long x_bs, int B, int C, int L, float* out) {
-  const int c = blockIdx.x;
-  float s = 0.f, dummy = 0.f;
-  for (int b = blockIdx.y; b < B; b += gridDim.y) {
-    const float* row = x + (long long)b * x_bs + (long long)c * L;
-    for (int t = threadIdx.x; t < L; t += 256) s += row[t];
+// ---------------------------------------------------------------- row sums (bias gradients)
+// out[c] = Σ_{b,t} x[b,c,t]: ONE 1024-thread workgroup per row c, every thread a strided run of 16-byte loads, a fixed
+// shuffle / LDS tree — the result is stored (no zero fill in front, no atomics), bit-identical from run to run.
+__device__ __forceinline__ float block_sum1024(float s) {
+  __shared__ float sw[16];
+  s = wave_sum(s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sw[wave] = s;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < 16; ++w) r += sw[w];
   }
-  block_sum2(s, dummy);
-  if (threadIdx.x == 0) atomicAdd(out + c, s);
+  return r;
 }
 
-__global__ __launch_bounds__(256) void row_sum_vec_kernel(const float* x, long long x_bs, int B, int C, int L, float* out, RowVec rv) {
-  const int c = blockIdx.x, r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
-  float s = 0.f, dummy = 0.f;
-  for (int b = blockIdx.y + r * gridDim.y; b < B; b += rpp * gridDim.y) {
+__global__ __launch_bounds__(1024) void row_sum_kernel(const float* x, long long x_bs, int B, int C, int L, float* out) {
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = threadIdx.x >> 6; b < B; b += 16) {           // a wave per batch row
+    const float* row = x + (long long)b * x_bs + (long long)c * L;
+    for (int t = threadIdx.x & 63; t < L; t += 64) s += row[t];
+  }
+  s = block_sum1024(s);
+  if (threadIdx.x == 0) out[c] = s;
+}
+
+__global__ __launch_bounds__(1024) void row_sum_vec_kernel(const float* x, long long x_bs, int B, int C, int L, float* out, RowVec rv) {
+  // threads-per-row = min(256, pow2ceil(L/4)); 1024/tpr batch rows in flight per pass
+  const int c = blockIdx.x, r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 1024 >> rv.shift;
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = r; b < B; b += rpp) {
     const float4* row = reinterpret_cast<const float4*>(x + (long long)b * x_bs + (long long)c * L);
     for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
       const float4 v = row[t];
-      s += (v.x + v.y) + (v.z + v.w);
+      s0 += v.x + v.y;
+      s1 += v.z + v.w;
     }
   }
-  block_sum2(s, dummy);
-  if (threadIdx.x == 0) atomicAdd(out + c, s);
+  const float s = block_sum1024(s0 + s1);
+  if (threadIdx.x == 0) out[c] = s;
 }
 
 extern "C" int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, void* stream) {
   FST_REQUIRE(x && out && B > 0 && C > 0 && L > 0, "fst_row_sum: bad arguments");
   FST_REQUIRE(B == 1 || x_bs >= (int64_t)C * L, "fst_row_sum: batch stride %lld < C*L = %lld", (long long)x_bs, (long long)C * L);
   if (vec_ok(L, {x}) && x_bs % 4 == 0)
-    hipLaunchKernelGGL(row_sum_vec_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, x,
-                       (long long)x_bs, B, C, L, out, row_vec(L));
+    hipLaunchKernelGGL(row_sum_vec_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, (long long)x_bs, B, C, L, out, row_vec(L));
   else
-    hipLaunchKernelGGL(row_sum_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, x,
-                       (long long)x_bs, B, C, L, out);
+    hipLaunchKernelGGL(row_sum_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, (long long)x_bs, B, C, L, out);
   FST_LAUNCH_CHECK();
   return 0;
 }
 
 // ---------------------------------------------------------------- BatchNorm
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int B, int C, int L, float* sums) {
+// Batch moments as (count, mean, M2 = Σ(x − mean)²) partials merged pairwise with Chan's formula — never Σx² − (Σx)²/N:
+// the 1x1 shortcut of a univariate extractor is y = w·x + b per channel, and a channel whose |w| happens to be small has
+// |mean| / std in the hundreds (903 measured at the metric configuration), where the textbook form loses every digit of
+// the variance in fp32 (found by tests/test_gpu_full_size.py: 8.7e-4 on the feature at B = 256, invisible at B = 4).
+// One workgroup per (channel, slot): a thread shifts its own samples by the first one it sees, lanes / waves merge
+// (n, mean, M2) triples, the workgroup stores ONE triple into its slot: no atomics, no zero fill, and the slots are merged
+// in a fixed order by fst_bn_finalize, so two runs give the same bits.
+struct Moments { float n, mean, m2; };
+
+__device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
+  const float n = a.n + b.n;
+  if (n == 0.f) return a;
+  const float d = b.mean - a.mean, fb = b.n / n;
+  Moments r;
+  r.n = n;
+  r.mean = a.mean + d * fb;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * fb;
+  return r;
+}
+
+// per-thread shifted sums -> triple
+__device__ __forceinline__ Moments thread_moments(float n, float k, float s1, float s2) {
+  Moments m = {n, 0.f, 0.f};
+  if (n > 0.f) {
+    m.mean = k + s1 / n;
+    m.m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
+  }
+  return m;
+}
+
+// workgroup-wide merge (256 threads); result valid in thread 0
+__device__ __forceinline__ Moments block_moments(Moments m) {
+  __shared__ float sm[4][3];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Moments q;
+    q.n = __shfl_down(m.n, o, 64); q.mean = __shfl_down(m.mean, o, 64); q.m2 = __shfl_down(m.m2, o, 64);
+    m = chan_merge(m, q);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sm[wave][0] = m.n; sm[wave][1] = m.mean; sm[wave][2] = m.m2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = {sm[0][0], sm[0][1], sm[0][2]};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) m = chan_merge(m, {sm[w][0], sm[w][1], sm[w][2]});
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int B, int C, int L, float* part) {
   const int c = blockIdx.x;
-  float s1 = 0.f, s2 = 0.f;
+  float n = 0.f, k = 0.f, s1 = 0.f, s2 = 0.f;
   for (int b = blockIdx.y; b < B; b += gridDim.y) {
     const float* row = y + ((long long)b * C + c) * L;
     for (int t = threadIdx.x; t < L; t += 256) {
       const float v = row[t];
-      s1 += v;
-      s2 += v * v;
+      if (n == 0.f) k = v;
+      const float d = v - k;
+      s1 += d; s2 += d * d; n += 1.f;
     }
   }
-  block_sum2(s1, s2);
+  const Moments m = block_moments(thread_moments(n, k, s1, s2));
   if (threadIdx.x == 0) {
-    atomicAdd(sums + c, s1);
-    atomicAdd(sums + C + c, s2);
+    float* o = part + ((long long)c * FST_BN_SLOTS + blockIdx.y) * 3;
+    o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
   }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_vec_kernel(const float* y, int B, int C, int L, float* sums, RowVec rv) {
+__global__ __launch_bounds__(256) void bn_stats_vec_kernel(const float* y, int B, int C, int L, float* part, RowVec rv) {
   const int c = blockIdx.x, r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
-  float s1 = 0.f, s2 = 0.f;
+  float n = 0.f, k = 0.f, s1 = 0.f, s2 = 0.f;
   for (int b = blockIdx.y + r * gridDim.y; b < B; b += rpp * gridDim.y) {
     const float4* row = reinterpret_cast<const float4*>(y + ((long long)b * C + c) * L);
     for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
       const float4 v = row[t];
-      s1 += (v.x + v.y) + (v.z + v.w);
-      s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      if (n == 0.f) k = v.x;
+      const float dx = v.x - k, dy = v.y - k, dz = v.z - k, dw = v.w - k;
+      s1 += (dx + dy) + (dz + dw);
+      s2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      n += 4.f;
     }
   }
-  block_sum2(s1, s2);
+  const Moments m = block_moments(thread_moments(n, k, s1, s2));
   if (threadIdx.x == 0) {
-    atomicAdd(sums + c, s1);
-    atomicAdd(sums + C + c, s2);
+    float* o = part + ((long long)c * FST_BN_SLOTS + blockIdx.y) * 3;
+    o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
   }
 }
 
-extern "C" int fst_bn_stats(const float* y, int B, int C, int L, float* sums, int64_t numel, void* stream) {
-  FST_REQUIRE(y && sums && B > 0 && C > 0 && L > 0, "fst_bn_stats: bad arguments");
+extern "C" int fst_bn_stats(const float* y, int B, int C, int L, float* part, int64_t numel, void* stream) {
+  FST_REQUIRE(y && part && B > 0 && C > 0 && L > 0, "fst_bn_stats: bad arguments");
   FST_REQUIRE_EXTENT("fst_bn_stats", B, C, L, numel);
+  // always FST_BN_SLOTS workgroups per channel: a slot without samples stores (0, 0, 0), so no slot is left unwritten
   if (vec_ok(L, {y}))
-    hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, y, B, C, L,
-                       sums, row_vec(L));
+    hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(C, FST_BN_SLOTS), dim3(256), 0, (hipStream_t)stream, y, B, C, L, part, row_vec(L));
   else
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, y, B, C, L, sums);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, FST_BN_SLOTS), dim3(256), 0, (hipStream_t)stream, y, B, C, L, part);
   FST_LAUNCH_CHECK();
   return 0;
 }
 
-__global__ void bn_finalize_kernel(const float* sums, const float* gamma, const float* beta, float* rmean, float* rvar,
-                                   int train, int N, int C, float eps, float momentum, float* stats) {
+__global__ void bn_finalize_kernel(const float* part, int n_slots, const float* gamma, const float* beta, float* rmean,
+                                   float* rvar, int train, int C, float eps, float momentum, float* stats) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float mean, var;
   if (train) {
-    const double m = (double)sums[c] / N;
-    double v = (double)sums[C + c] / N - m * m;
-    if (v < 0) v = 0;
+    // slots merged in index order, in double: deterministic, and exact enough that the order would not matter anyway
+    double n = 0.0, m = 0.0, m2 = 0.0;
+    const float* q = part + (long long)c * n_slots * 3;
+    for (int s = 0; s < n_slots; ++s) {
+      const double nb = q[3 * s], mb = q[3 * s + 1], Mb = q[3 * s + 2];
+      if (nb <= 0.0) continue;
+      const double nn = n + nb, d = mb - m;
+      m += d * (nb / nn);
+      m2 += Mb + d * d * (n * nb / nn);
+      n = nn;
+    }
+    const double v = n > 0.0 ? m2 / n : 0.0;
     mean = (float)m;
     var = (float)v;
-    const float unbiased = N > 1 ? (float)(v * ((double)N / (N - 1))) : var;
+    const float unbiased = n > 1.0 ? (float)(m2 / (n - 1.0)) : var;
     rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
     rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
   } else {
@@ -205,14 +283,12 @@ __global__ void bn_finalize_kernel(const float* sums, const float* gamma, const 
   stats[3 * C + c] = beta[c] - mean * scale;
 }
 
-extern "C" int fst_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean,
-                               float* running_var, int train, int B_total, int C, int L, float eps, float momentum,
-                               float* stats, void* stream) {
+extern "C" int fst_bn_finalize(const float* part, int n_slots, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int train, int C, float eps, float momentum, float* stats, void* stream) {
   FST_REQUIRE(gamma && beta && running_mean && running_var && stats && C > 0, "fst_bn_finalize: bad arguments");
-  FST_REQUIRE(!train || sums, "fst_bn_finalize: train mode needs sums");
-  FST_REQUIRE(!train || (B_total > 0 && L > 0), "fst_bn_finalize: B_total=%d L=%d", B_total, L);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, gamma, beta,
-                     running_mean, running_var, train, B_total * L, C, eps, momentum, stats);
+  FST_REQUIRE(!train || (part && n_slots > 0), "fst_bn_finalize: train mode needs the moment partials (n_slots=%d)", n_slots);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, n_slots, gamma, beta,
+                     running_mean, running_var, train, C, eps, momentum, stats);
   FST_LAUNCH_CHECK();
   return 0;
 }
@@ -291,8 +367,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* dy, con
   }
   block_sum2(s1, s2);
   if (threadIdx.x == 0) {
-    atomicAdd(red + c, s1);
-    atomicAdd(red + C + c, s2);
+    red[(long long)c * FST_BN_SLOTS + blockIdx.y] = s1;
+    red[((long long)C + c) * FST_BN_SLOTS + blockIdx.y] = s2;
   }
 }
 
@@ -323,8 +399,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* dy,
   }
   block_sum2(s1, s2);
   if (threadIdx.x == 0) {
-    atomicAdd(red + c, s1);
-    atomicAdd(red + C + c, s2);
+    red[(long long)c * FST_BN_SLOTS + blockIdx.y] = s1;
+    red[((long long)C + c) * FST_BN_SLOTS + blockIdx.y] = s2;
   }
 }
 
@@ -333,22 +409,36 @@ extern "C" int fst_bn_bwd_reduce(const float* dy, const float* y, const float* o
   FST_REQUIRE(dy && y && stats && red && (!relu || out) && B > 0 && C > 0 && L > 0, "fst_bn_bwd_reduce: bad arguments");
   FST_REQUIRE_EXTENT("fst_bn_bwd_reduce", B, C, L, numel);
   if (vec_ok(L, {dy, y, out}))
-    hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, dy,
+    hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel, dim3(C, FST_BN_SLOTS), dim3(256), 0, (hipStream_t)stream, dy,
                        y, out, stats, B, C, L, relu, red, row_vec(L));
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, B < CH_SPLIT ? B : CH_SPLIT), dim3(256), 0, (hipStream_t)stream, dy, y,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, FST_BN_SLOTS), dim3(256), 0, (hipStream_t)stream, dy, y,
                        out, stats, B, C, L, relu, red);
   FST_LAUNCH_CHECK();
   return 0;
 }
 
+// red: [2][C][n_slots] partial sums (n_slots = FST_BN_SLOTS straight from fst_bn_bwd_reduce, or 1 once the caller has added
+// them, e.g. across ranks), added here in slot order.  red_out (optional, [2C]): the slot sums = (dβ, dγ), written by the
+// threads of batch row 0 — the parameter gradients need no reduction launch of their own.
+__device__ __forceinline__ void bn_red_sums(const float* red, int n_slots, int C, int c, float& r1, float& r2) {
+  r1 = 0.f; r2 = 0.f;
+  for (int s = 0; s < n_slots; ++s) {
+    r1 += red[(long long)c * n_slots + s];
+    r2 += red[((long long)C + c) * n_slots + s];
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* y, const float* out,
-                                                           const float* stats, const float* red, float* dx, int C, int L,
-                                                           int relu, int train, float invN) {
+                                                           const float* stats, const float* red, int n_slots, float* red_out,
+                                                           float* dx, int C, int L, int relu, int train, float invN) {
   const int bc = blockIdx.x;
   const int c = bc % C;
   const float mean = stats[c], invstd = stats[C + c], scale = stats[2 * C + c];
-  const float m1 = train ? red[c] * invN : 0.f, m2 = train ? red[C + c] * invN : 0.f;
+  float r1 = 0.f, r2 = 0.f;
+  if (red) bn_red_sums(red, n_slots, C, c, r1, r2);
+  if (red_out && bc < C && threadIdx.x == 0) { red_out[c] = r1; red_out[C + c] = r2; }
+  const float m1 = train ? r1 * invN : 0.f, m2 = train ? r2 * invN : 0.f;
   const long long base = (long long)bc * L;
   for (int t = threadIdx.x; t < L; t += 256) {
     float g = dy[base + t];
@@ -359,14 +449,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* dy, const float* y, const float* out,
-                                                               const float* stats, const float* red, float* dx, int rows,
-                                                               int C, int L, int relu, int train, float invN, RowVec rv) {
+                                                               const float* stats, const float* red, int n_slots,
+                                                               float* red_out, float* dx, int rows, int C, int L, int relu,
+                                                               int train, float invN, RowVec rv) {
   const int r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
   const int bc = blockIdx.x * rpp + r;
   if (bc >= rows) return;
   const int c = bc % C;
   const float mean = stats[c], invstd = stats[C + c], scale = stats[2 * C + c];
-  const float m1 = train ? red[c] * invN : 0.f, m2 = train ? red[C + c] * invN : 0.f;
+  float r1 = 0.f, r2 = 0.f;
+  if (red) bn_red_sums(red, n_slots, C, c, r1, r2);
+  if (red_out && bc < C && t0 == 0) { red_out[c] = r1; red_out[C + c] = r2; }
+  const float m1 = train ? r1 * invN : 0.f, m2 = train ? r2 * invN : 0.f;
   const long long base = (long long)bc * rv.L4;
   const float4* dy4 = reinterpret_cast<const float4*>(dy) + base;
   const float4* y4 = reinterpret_cast<const float4*>(y) + base;
@@ -392,19 +486,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* dy, 
 }
 
 extern "C" int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
-                                float* dx, int B, int C, int L, int relu, int train, int B_total, int64_t numel,
-                                void* stream) {
+                                int n_slots, float* red_out, float* dx, int B, int C, int L, int relu, int train, int B_total,
+                                int64_t numel, void* stream) {
   FST_REQUIRE(dy && y && stats && dx && (!relu || out) && (!train || red), "fst_bn_bwd_apply: bad arguments");
   FST_REQUIRE(B > 0 && C > 0 && L > 0 && B_total >= B, "fst_bn_bwd_apply: B=%d C=%d L=%d B_total=%d", B, C, L, B_total);
+  FST_REQUIRE(!red || n_slots > 0, "fst_bn_bwd_apply: n_slots=%d", n_slots);
+  FST_REQUIRE(!red_out || red, "fst_bn_bwd_apply: red_out needs red");
   FST_REQUIRE_EXTENT("fst_bn_bwd_apply", B, C, L, numel);     // the launch walks B (not B_total) samples
   if (vec_ok(L, {dy, y, out, dx})) {
     const RowVec rv = row_vec(L);
     const int rpp = 256 >> rv.shift;
     hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((B * C + rpp - 1) / rpp), dim3(256), 0, (hipStream_t)stream, dy, y, out,
-                       stats, red, dx, B * C, C, L, relu, train, 1.0f / ((float)B_total * (float)L), rv);
+                       stats, red, n_slots, red_out, dx, B * C, C, L, relu, train, 1.0f / ((float)B_total * (float)L), rv);
   } else {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, y, out, stats, red, dx, C, L,
-                       relu, train, 1.0f / ((float)B_total * (float)L));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, y, out, stats, red, n_slots,
+                       red_out, dx, C, L, relu, train, 1.0f / ((float)B_total * (float)L));
   }
   FST_LAUNCH_CHECK();
   return 0;

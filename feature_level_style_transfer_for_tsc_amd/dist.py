@@ -118,6 +118,29 @@ def sum_over_ranks_(t: torch.Tensor) -> int:
     return _GLOBAL.world
 
 
+def _all_gather_cat(x: torch.Tensor, dim: int, group) -> torch.Tensor:
+    """Every rank's ``x`` concatenated along ``dim`` in rank order (no gradient).  RCCL: one all_gather_into_tensor of the
+    payload; other backends (gloo in the CPU tests): own block + all-reduce(SUM) of a zero-padded buffer."""
+    n, r = dist.get_world_size(group), dist.get_rank(group)
+    x = x.detach().contiguous()
+    if dist.get_backend(group) == "nccl":
+        out = x.new_empty((n,) + tuple(x.shape))
+        dist.all_gather_into_tensor(out, x, group=group)
+        return torch.cat(list(out.unbind(0)), dim=dim) if dim != 0 else out.view((n * x.shape[0],) + tuple(x.shape[1:]))
+    shape = list(x.shape)
+    b = shape[dim]
+    shape[dim] = n * b
+    out = x.new_zeros(shape)
+    out.narrow(dim, r * b, b).copy_(x)
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
+def gather_slots(part: torch.Tensor) -> torch.Tensor:
+    """BatchNorm moment partials [C, slots, 3] of every rank as [C, world·slots, 3] (identity outside the context)."""
+    return part if _GLOBAL is None else _all_gather_cat(part, 1, _GLOBAL.group)
+
+
 class _AllReduceMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -142,14 +165,8 @@ def mean_over_ranks(x: torch.Tensor) -> torch.Tensor:
 class _GatherCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dim):
-        n, r = _GLOBAL.world, dist.get_rank(_GLOBAL.group)
-        shape = list(x.shape)
-        b = shape[dim]
-        shape[dim] = n * b
-        out = x.new_zeros(shape)                        # own block + all-reduce(SUM): works on every backend
-        out.narrow(dim, r * b, b).copy_(x.detach())
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=_GLOBAL.group)
-        ctx.group, ctx.dim, ctx.b, ctx.r = _GLOBAL.group, dim, b, r
+        out = _all_gather_cat(x, dim, _GLOBAL.group)    # RCCL: all_gather_into_tensor (1/N of the padded all-reduce's bytes)
+        ctx.group, ctx.dim, ctx.b, ctx.r = _GLOBAL.group, dim, x.shape[dim], dist.get_rank(_GLOBAL.group)
         return out
 
     @staticmethod

@@ -292,7 +292,7 @@ def row_sum(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     bs, L = _ncl(x, "x")
     B, C = x.size(0), x.size(1)
     if out is None:
-        out = torch.zeros(C, device=x.device, dtype=torch.float32)
+        out = torch.empty(C, device=x.device, dtype=torch.float32)          # written, not accumulated: no zero fill
     check(lib.fst_row_sum(ptr(x), bs, B, C, L, ptr(out), stream_ptr()), "fst_row_sum")
     return out
 
@@ -577,19 +577,22 @@ def mask_taps_(w: Tensor, lo: Tensor, hi: Tensor) -> None:
 # --------------------------------------------------------------------------------------------------
 # BatchNorm1d (+ReLU, + second BN'd branch) over (B, L)
 # --------------------------------------------------------------------------------------------------
+BN_SLOTS = 16      # FST_BN_SLOTS of include/fst_hip.h: workgroups (= partial results) per channel of the BatchNorm reductions
+
+
 def _bn_stats(y: Tensor, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tensor, training: bool, eps: float,
               momentum: float) -> Tensor:
     lib = _lib.load()
     B, C, L = y.shape
     stats = torch.empty(4 * C, device=y.device, dtype=torch.float32)
-    sums = None
+    part, n_slots = None, 0
     if training:
-        sums = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
-        check(lib.fst_bn_stats(ptr(y), B, C, L, ptr(sums), y.numel(), stream_ptr()), "fst_bn_stats")
-        B_total = _dist.sum_over_ranks_(sums) * B        # global-batch mode: moments over every rank's samples (SyncBN)
-    else:
-        B_total = B
-    check(lib.fst_bn_finalize(ptr(sums), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), int(training), B_total, C, L, eps,
+        # (count, mean, M2) per (channel, slot), written by the kernel (no zero fill), merged in slot order by fst_bn_finalize
+        part = torch.empty(C, BN_SLOTS, 3, device=y.device, dtype=torch.float32)
+        check(lib.fst_bn_stats(ptr(y), B, C, L, ptr(part), y.numel(), stream_ptr()), "fst_bn_stats")
+        part = _dist.gather_slots(part)                  # global-batch mode (SyncBN): every rank's slots, in rank order
+        n_slots = part.size(1)
+    check(lib.fst_bn_finalize(ptr(part), n_slots, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), int(training), C, eps,
                               momentum, ptr(stats), stream_ptr()), "fst_bn_finalize")
     return stats
 
@@ -598,21 +601,28 @@ def _bn_backward(dy: Tensor, y: Tensor, out: Optional[Tensor], stats: Tensor, re
                  need_dx: bool = True):
     lib = _lib.load()
     B, C, L = y.shape
-    red = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
-    check(lib.fst_bn_bwd_reduce(ptr(dy), ptr(y), ptr(out), ptr(stats), B, C, L, int(relu), ptr(red), _same_numel(dy, y, out),
+    # per-slot partial sums [2][C][slots] (Σ dy', Σ dy'·x̂), written by the kernel; fst_bn_bwd_apply adds the slots in order and
+    # leaves the totals (dβ | dγ) in ``red`` — no zero fill, no atomics, no reduction launch
+    part = torch.empty(2, C, BN_SLOTS, device=y.device, dtype=torch.float32)
+    check(lib.fst_bn_bwd_reduce(ptr(dy), ptr(y), ptr(out), ptr(stats), B, C, L, int(relu), ptr(part), _same_numel(dy, y, out),
                                 stream_ptr()),
           "fst_bn_bwd_reduce")
-    dx = None
-    if need_dx:
-        dx = torch.empty_like(y)
-        red_g, B_total = red, B
-        if training and _dist.global_batch_active():
-            # the two batch means of the backward formula run over every rank's samples; the parameter gradients
-            # (returned below) stay local sums — the gradient bucket averages them like every other parameter
-            red_g = red.clone()
-            B_total = _dist.sum_over_ranks_(red_g) * B
-        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(red_g), ptr(dx), B, C, L, int(relu),
+    if not need_dx:
+        red = part.sum(dim=2).view(2 * C)
+        return None, red[C:], red[:C]
+    dx = torch.empty_like(y)
+    if training and _dist.global_batch_active():
+        # the two batch means of the backward formula run over every rank's samples; the parameter gradients
+        # (returned below) stay local sums — the gradient bucket averages them like every other parameter
+        red = part.sum(dim=2).view(2 * C)
+        red_g = red.clone()
+        B_total = _dist.sum_over_ranks_(red_g) * B
+        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(red_g), 1, None, ptr(dx), B, C, L, int(relu),
                                    int(training), B_total, _same_numel(dy, y, out, dx), stream_ptr()), "fst_bn_bwd_apply")
+    else:
+        red = torch.empty(2 * C, device=y.device, dtype=torch.float32)
+        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(part), BN_SLOTS, ptr(red), ptr(dx), B, C, L,
+                                   int(relu), int(training), B, _same_numel(dy, y, out, dx), stream_ptr()), "fst_bn_bwd_apply")
     return dx, red[C:], red[:C]                                   # dx, dgamma, dbeta
 
 

@@ -127,7 +127,7 @@ int fst_conv_wgrad(const float* x0, int64_t x0_bs, const float* x1, int64_t x1_b
                    float* da_packed, const int32_t* plan_dev, const int32_t* plan_host, int plan_len,
                    int B, int L, int M, int ksplit, int flags /* 0 or FST_GEMM_BF16X3 */, int64_t x0_mul_off, void* stream);
 
-/* out[m] (+)= Σ_{b,t} x[b,m,t]   (bias gradients; BN β gradient). */
+/* out[m] = Σ_{b,t} x[b,m,t]   (bias gradients): one workgroup per row, written (no zero fill, no atomics, fixed order). */
 int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -139,22 +139,32 @@ int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, v
  * from the tensors it holds — NOT recomputed from B, C, L.  The launcher refuses B*C*L != numel before launching, so a
  * batch argument that does not describe the buffers (the cause of round 1's GPU memory fault: the all-rank batch
  * passed as the launch batch of fst_bn_bwd_apply) is an error return, never an out-of-bounds walk. */
-int fst_bn_stats(const float* y, int B, int C, int L, float* sums /* [2*C], zeroed by caller */, int64_t numel, void* stream);
-/* sums = (Σx, Σx²) over B_total·L samples per channel: B_total is the batch the moments run over — the local batch,
- * or in global-batch data parallelism (SyncBN) the sum of every rank's batch after the caller all-reduced sums. */
-int fst_bn_finalize(const float* sums, const float* gamma, const float* beta,
-                    float* running_mean, float* running_var, int train,
-                    int B_total, int C, int L, float eps, float momentum, float* stats, void* stream);
+/* Batch moments as partials: part[c][slot] = (count, mean, M2 = Σ(x − mean)²) of the samples workgroup `slot` of channel c
+ * walked — FST_BN_SLOTS slots per channel, every one written (no zero fill by the caller, no atomics).  Merged with Chan's
+ * formula, never as Σx² − (Σx)²/N: a channel of the univariate extractor's 1x1 shortcut has |mean|/std in the hundreds. */
+#define FST_BN_SLOTS 16
+int fst_bn_stats(const float* y, int B, int C, int L, float* part /* [C][FST_BN_SLOTS][3], written */, int64_t numel, void* stream);
+/* Merges the n_slots partials of every channel in slot order (double precision) into the batch mean / biased variance, updates
+ * the running statistics (unbiased variance) and writes stats.  n_slots = FST_BN_SLOTS, or ranks·FST_BN_SLOTS in global-batch
+ * data parallelism (SyncBN) after the caller gathered every rank's partials as part[c][rank·FST_BN_SLOTS + slot].
+ * train = 0: part may be NULL; stats from the running statistics. */
+int fst_bn_finalize(const float* part, int n_slots, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int train, int C, float eps, float momentum,
+                    float* stats, void* stream);
 /* out = act(y*scale + shift (+ res*res_scale + res_shift | + res)) */
 int fst_bn_apply(const float* y, const float* stats, const float* res, const float* res_stats,
                  float* out, int B, int C, int L, int relu, int64_t numel, void* stream);
-/* reductions for backward: red[c] = Σ dyʹ, red[C+c] = Σ dyʹ·x̂, with dyʹ = dy·[out>0] when relu */
+/* reductions for backward, as FST_BN_SLOTS partial sums per channel (written, no zero fill, no atomics):
+ * red[0][c][slot] = Σ dyʹ, red[1][c][slot] = Σ dyʹ·x̂, with dyʹ = dy·[out>0] when relu */
 int fst_bn_bwd_reduce(const float* dy, const float* y, const float* out, const float* stats,
-                      int B, int C, int L, int relu, float* red /* [2*C] zeroed */, int64_t numel, void* stream);
-/* dx = scale·(dyʹ − red0/N − x̂·red1/N) in train mode, scale·dyʹ in eval mode; N = B_total·L.  B is the batch of
- * the tensors (launch shape); B_total >= B the batch red was summed over (= B, or all ranks' batches for SyncBN). */
-int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
-                     float* dx, int B, int C, int L, int relu, int train, int B_total, int64_t numel, void* stream);
+                      int B, int C, int L, int relu, float* red /* [2][C][FST_BN_SLOTS] */, int64_t numel, void* stream);
+/* dx = scale·(dyʹ − r0/N − x̂·r1/N) in train mode, scale·dyʹ in eval mode; r = the n_slots partials of red added in slot order
+ * (n_slots = FST_BN_SLOTS as fst_bn_bwd_reduce leaves them, or 1 when the caller has already added them, e.g. over ranks);
+ * N = B_total·L.  B is the batch of the tensors (launch shape); B_total >= B the batch red was summed over (= B, or all
+ * ranks' batches for SyncBN).  red_out (optional, [2C]): receives (r0 | r1) = (dβ | dγ). */
+int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red, int n_slots,
+                     float* red_out, float* dx, int B, int C, int L, int relu, int train, int B_total, int64_t numel,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * WaveGlow pieces — Simplified_NF_WaveGlow.py

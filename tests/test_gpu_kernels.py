@@ -189,6 +189,33 @@ def test_batch_norm(training, relu, L):
     assert_close(rvd, rv_ref, 1e-5, "running var")
 
 
+@pytest.mark.parametrize("B,L", [(256, 512), (7, 70)])
+def test_batch_norm_moments_of_an_ill_conditioned_channel(B, L):
+    """|mean| / std in the hundreds (the 1x1 shortcut of a univariate extractor, y = w·x + b with a small |w|: 903 measured at
+    the metric configuration): Σx² − (Σx)²/N in fp32 has no correct digit of the variance there.  The kernels merge
+    (count, mean, M2) partials instead — checked against fp64 — and give the same bits on every run (no atomics)."""
+    g = torch.Generator().manual_seed(31)
+    C = 6
+    ratio = torch.tensor([0.0, 3.0, 50.0, 900.0, 2.0e4, 900.0])
+    std = torch.tensor([1.0, 0.5, 0.02, 1e-3, 1e-3, 5.0])
+    y = (torch.randn(B, C, L, generator=g, dtype=torch.float64) * std.view(1, C, 1) + (ratio * std).view(1, C, 1)).float()
+    yd = y.to(DEV)
+    gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    outs = []
+    for _ in range(2):
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        outs.append((ops.BNActFn.apply(yd, gamma, beta, rm, rv, True, False, 0.0, 0.1), rm, rv))
+    m64, v64 = y.double().mean(dim=(0, 2)), y.double().var(dim=(0, 2), unbiased=False)
+    want = (y.double() - m64.view(1, C, 1)) / torch.sqrt(v64.view(1, C, 1))
+    out, rm, rv = outs[0]
+    # the input itself is fp32: (x − mean) carries eps·|mean| of representation error, i.e. eps·ratio of a standard deviation
+    for c in range(C):
+        tol = 2e-5 + 3e-7 * float(ratio[c])
+        assert_close(out[:, c], want[:, c], tol, f"normalised channel {c} (|mean|/std = {float(ratio[c]):g})")
+    assert_close(rv, 0.9 + 0.1 * y.double().var(dim=(0, 2), unbiased=True), 1e-5, "running variance")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]), "two runs differ: the reduction is not deterministic"
+
+
 @pytest.mark.parametrize("L", [50, 52, 512])
 def test_bn_add_bn_relu(L):
     g = torch.Generator().manual_seed(4)
@@ -348,20 +375,22 @@ def test_batch_norm_global_batch_arguments_stay_inside_their_buffers():
     (ybuf, y), (dybuf, dy), (dxbuf, dx) = padded(y_h), padded(dy_h), padded()
     gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
     rmean, rvar = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-    sums = torch.zeros(2 * C, device=DEV)
-    _lib.check(lib.fst_bn_stats(y.data_ptr(), B, C, L, sums.data_ptr(), n, _lib.stream_ptr()), "bn_stats")
+    part = torch.full((C, ops.BN_SLOTS, 3), CANARY, device=DEV)      # every slot must be written by the kernel (no zero fill)
+    _lib.check(lib.fst_bn_stats(y.data_ptr(), B, C, L, part.data_ptr(), n, _lib.stream_ptr()), "bn_stats")
+    assert float(part[:, :, 0].sum(dim=1).min()) == B * L and float(part[:, :, 0].sum(dim=1).max()) == B * L
     B_total = 3 * B
-    sums_g = sums * 3                                               # as if two more ranks held the same samples
+    part_g = part.repeat(1, 3, 1).contiguous()                      # as if two more ranks held the same samples
     stats = torch.empty(4 * C, device=DEV)
-    _lib.check(lib.fst_bn_finalize(sums_g.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), 1,
-                                   B_total, C, L, 1e-5, 0.1, stats.data_ptr(), _lib.stream_ptr()), "bn_finalize")
+    _lib.check(lib.fst_bn_finalize(part_g.data_ptr(), 3 * ops.BN_SLOTS, gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(),
+                                   rvar.data_ptr(), 1, C, 1e-5, 0.1, stats.data_ptr(), _lib.stream_ptr()), "bn_finalize")
     assert_close(stats[:C], y_h.mean(dim=(0, 2)), 1e-5, "mean over B_total*L samples")
-    red = torch.zeros(2 * C, device=DEV)
+    assert_close(1.0 / stats[C: 2 * C].double() ** 2 - 1e-5, y_h.double().var(dim=(0, 2), unbiased=False), 1e-5, "variance over B_total*L samples")
+    red = torch.full((2, C, ops.BN_SLOTS), CANARY, device=DEV)
     _lib.check(lib.fst_bn_bwd_reduce(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), B, C, L, 0, red.data_ptr(), n,
                                      _lib.stream_ptr()), "bn_bwd_reduce")
-    red_g = red * 3
-    _lib.check(lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), dx.data_ptr(), B, C, L,
-                                    0, 1, B_total, n, _lib.stream_ptr()), "bn_bwd_apply")
+    red_g = (red.sum(dim=2) * 3).view(2 * C).contiguous()
+    _lib.check(lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), 1, None, dx.data_ptr(),
+                                    B, C, L, 0, 1, B_total, n, _lib.stream_ptr()), "bn_bwd_apply")
     torch.cuda.synchronize()
     for name, buf in (("y", ybuf), ("dy", dybuf), ("dx", dxbuf)):
         assert bool((buf[:PAD] == CANARY).all()) and bool((buf[PAD + n:] == CANARY).all()), f"{name}: padding was written"
@@ -373,8 +402,8 @@ def test_batch_norm_global_batch_arguments_stay_inside_their_buffers():
         dyd - dyd.mean(dim=(0, 2), keepdim=True) - xh * (dyd * xh).mean(dim=(0, 2), keepdim=True))
     assert_close(dx, want, 1e-4, "dx with B_total = 3B")
     # (3) the round-1 bug itself — the global batch passed as the launch batch — is now an error return, not a walk
-    rc = lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), dx.data_ptr(), B_total, C, L,
-                              0, 1, B_total, n, _lib.stream_ptr())
+    rc = lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), 1, None, dx.data_ptr(),
+                              B_total, C, L, 0, 1, B_total, n, _lib.stream_ptr())
     assert rc < 0 and b"element count" in lib.fst_last_error()
     rc = lib.fst_bn_apply(y.data_ptr(), stats.data_ptr(), None, None, dx.data_ptr(), B_total, C, L, 0, n, _lib.stream_ptr())
     assert rc < 0
