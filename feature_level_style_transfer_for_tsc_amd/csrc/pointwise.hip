@@ -146,100 +146,60 @@ extern "C" int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, fl
 }
 
 // ---------------------------------------------------------------- BatchNorm
-// Batch moments as (count, mean, M2 = Σ(x − mean)²) partials merged pairwise with Chan's formula — never Σx² − (Σx)²/N:
-// the 1x1 shortcut of a univariate extractor is y = w·x + b per channel, and a channel whose |w| happens to be small has
-// |mean| / std in the hundreds (903 measured at the metric configuration), where the textbook form loses every digit of
-// the variance in fp32 (found by tests/test_gpu_full_size.py: 8.7e-4 on the feature at B = 256, invisible at B = 4).
-// One workgroup per (channel, slot): a thread shifts its own samples by the first one it sees, lanes / waves merge
-// (n, mean, M2) triples, the workgroup stores ONE triple into its slot: no atomics, no zero fill, and the slots are merged
-// in a fixed order by fst_bn_finalize, so two runs give the same bits.
-struct Moments { float n, mean, m2; };
-
-__device__ __forceinline__ Moments chan_merge(Moments a, Moments b) {
-  const float n = a.n + b.n;
-  if (n == 0.f) return a;
-  const float d = b.mean - a.mean, fb = b.n / n;
-  Moments r;
-  r.n = n;
-  r.mean = a.mean + d * fb;
-  r.m2 = a.m2 + b.m2 + d * d * a.n * fb;
-  return r;
-}
-
-// per-thread shifted sums -> triple
-__device__ __forceinline__ Moments thread_moments(float n, float k, float s1, float s2) {
-  Moments m = {n, 0.f, 0.f};
-  if (n > 0.f) {
-    m.mean = k + s1 / n;
-    m.m2 = fmaxf(s2 - s1 * s1 / n, 0.f);
-  }
-  return m;
-}
-
-// workgroup-wide merge (256 threads); result valid in thread 0
-__device__ __forceinline__ Moments block_moments(Moments m) {
-  __shared__ float sm[4][3];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    Moments q;
-    q.n = __shfl_down(m.n, o, 64); q.mean = __shfl_down(m.mean, o, 64); q.m2 = __shfl_down(m.m2, o, 64);
-    m = chan_merge(m, q);
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { sm[wave][0] = m.n; sm[wave][1] = m.mean; sm[wave][2] = m.m2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = {sm[0][0], sm[0][1], sm[0][2]};
-#pragma unroll
-    for (int w = 1; w < 4; ++w) m = chan_merge(m, {sm[w][0], sm[w][1], sm[w][2]});
-  }
-  return m;
-}
-
+// Batch moments from SHIFTED sums, never Σx² − (Σx)²/N of the raw values: the 1x1 shortcut of a univariate extractor is
+// y = w·x + b per channel, and a channel whose |w| happens to be small has |mean| / std in the hundreds (903 measured at the
+// metric configuration), where the textbook form loses every digit of the variance in fp32 (found by
+// tests/test_gpu_full_size.py: 8.7e-4 on the feature at B = 256, invisible at B = 4).  Every workgroup of a channel shifts by
+// the same sample k = y[0, c, 0], so |x − k| is of the order of the standard deviation and the fp32 sums of (x − k) and
+// (x − k)² carry ~1e-6; the slot stores (count, k, Σ(x−k), Σ(x−k)²) and fst_bn_finalize turns the slots into (count, mean, M2)
+// and merges them with Chan's formula IN DOUBLE, in slot order: no atomics, no zero fill, the same bits on every run, and
+// slots of other ranks (their own shifts) merge the same way.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, int B, int C, int L, float* part) {
   const int c = blockIdx.x;
-  float n = 0.f, k = 0.f, s1 = 0.f, s2 = 0.f;
+  const float k = y[(long long)c * L];
+  float s1 = 0.f, s2 = 0.f;
+  int n = 0;
   for (int b = blockIdx.y; b < B; b += gridDim.y) {
     const float* row = y + ((long long)b * C + c) * L;
     for (int t = threadIdx.x; t < L; t += 256) {
-      const float v = row[t];
-      if (n == 0.f) k = v;
-      const float d = v - k;
-      s1 += d; s2 += d * d; n += 1.f;
+      const float d = row[t] - k;
+      s1 += d; s2 += d * d;
     }
+    n += L;
   }
-  const Moments m = block_moments(thread_moments(n, k, s1, s2));
+  block_sum2(s1, s2);
   if (threadIdx.x == 0) {
-    float* o = part + ((long long)c * FST_BN_SLOTS + blockIdx.y) * 3;
-    o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
+    float* o = part + ((long long)c * FST_BN_SLOTS + blockIdx.y) * 4;
+    o[0] = (float)n; o[1] = k; o[2] = s1; o[3] = s2;
   }
 }
 
 __global__ __launch_bounds__(256) void bn_stats_vec_kernel(const float* y, int B, int C, int L, float* part, RowVec rv) {
   const int c = blockIdx.x, r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
-  float n = 0.f, k = 0.f, s1 = 0.f, s2 = 0.f;
+  const float k = y[(long long)c * L];
+  float s1 = 0.f, s2 = 0.f;
   for (int b = blockIdx.y + r * gridDim.y; b < B; b += rpp * gridDim.y) {
     const float4* row = reinterpret_cast<const float4*>(y + ((long long)b * C + c) * L);
     for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
       const float4 v = row[t];
-      if (n == 0.f) k = v.x;
       const float dx = v.x - k, dy = v.y - k, dz = v.z - k, dw = v.w - k;
       s1 += (dx + dy) + (dz + dw);
       s2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-      n += 4.f;
     }
   }
-  const Moments m = block_moments(thread_moments(n, k, s1, s2));
+  block_sum2(s1, s2);
   if (threadIdx.x == 0) {
-    float* o = part + ((long long)c * FST_BN_SLOTS + blockIdx.y) * 3;
-    o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
+    // batch rows of this slot: b = y + j·gridDim.y < B
+    const int rows = blockIdx.y < B ? (B - 1 - blockIdx.y) / gridDim.y + 1 : 0;
+    float* o = part + ((long long)c * FST_BN_SLOTS + blockIdx.y) * 4;
+    o[0] = (float)rows * (float)L; o[1] = k; o[2] = s1; o[3] = s2;
   }
 }
 
 extern "C" int fst_bn_stats(const float* y, int B, int C, int L, float* part, int64_t numel, void* stream) {
   FST_REQUIRE(y && part && B > 0 && C > 0 && L > 0, "fst_bn_stats: bad arguments");
   FST_REQUIRE_EXTENT("fst_bn_stats", B, C, L, numel);
-  // always FST_BN_SLOTS workgroups per channel: a slot without samples stores (0, 0, 0), so no slot is left unwritten
+  // always FST_BN_SLOTS workgroups per channel: a slot without samples stores a zero count, so no slot is left unwritten
   if (vec_ok(L, {y}))
     hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(C, FST_BN_SLOTS), dim3(256), 0, (hipStream_t)stream, y, B, C, L, part, row_vec(L));
   else
@@ -256,10 +216,14 @@ __global__ void bn_finalize_kernel(const float* part, int n_slots, const float* 
   if (train) {
     // slots merged in index order, in double: deterministic, and exact enough that the order would not matter anyway
     double n = 0.0, m = 0.0, m2 = 0.0;
-    const float* q = part + (long long)c * n_slots * 3;
+    const float* q = part + (long long)c * n_slots * 4;
     for (int s = 0; s < n_slots; ++s) {
-      const double nb = q[3 * s], mb = q[3 * s + 1], Mb = q[3 * s + 2];
+      const double nb = q[4 * s];
       if (nb <= 0.0) continue;
+      const double s1 = q[4 * s + 2], s2 = q[4 * s + 3];
+      const double mb = (double)q[4 * s + 1] + s1 / nb;                  // the slot's mean and M2 from its shifted sums
+      double Mb = s2 - s1 * s1 / nb;
+      if (Mb < 0.0) Mb = 0.0;
       const double nn = n + nb, d = mb - m;
       m += d * (nb / nn);
       m2 += Mb + d * d * (n * nb / nn);

@@ -137,7 +137,7 @@ def _all_gather_cat(x: torch.Tensor, dim: int, group) -> torch.Tensor:
 
 
 def gather_slots(part: torch.Tensor) -> torch.Tensor:
-    """BatchNorm moment partials [C, slots, 3] of every rank as [C, world·slots, 3] (identity outside the context)."""
+    """BatchNorm moment partials [C, slots, 4] of every rank as [C, world·slots, 4] (identity outside the context)."""
     return part if _GLOBAL is None else _all_gather_cat(part, 1, _GLOBAL.group)
 
 

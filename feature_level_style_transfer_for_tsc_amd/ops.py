@@ -587,8 +587,9 @@ def _bn_stats(y: Tensor, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tenso
     stats = torch.empty(4 * C, device=y.device, dtype=torch.float32)
     part, n_slots = None, 0
     if training:
-        # (count, mean, M2) per (channel, slot), written by the kernel (no zero fill), merged in slot order by fst_bn_finalize
-        part = torch.empty(C, BN_SLOTS, 3, device=y.device, dtype=torch.float32)
+        # (count, shift, Σ(x−shift), Σ(x−shift)²) per (channel, slot), written by the kernel (no zero fill), merged in slot order by
+        # fst_bn_finalize
+        part = torch.empty(C, BN_SLOTS, 4, device=y.device, dtype=torch.float32)
         check(lib.fst_bn_stats(ptr(y), B, C, L, ptr(part), y.numel(), stream_ptr()), "fst_bn_stats")
         part = _dist.gather_slots(part)                  # global-batch mode (SyncBN): every rank's slots, in rank order
         n_slots = part.size(1)
@@ -780,24 +781,34 @@ def wn_pack_bwd(rs_w: Tensor, n: int, last: bool) -> Tensor:
     return img
 
 
+def wn_bwd_partials(n_layers: int, B: int, L: int, device) -> Tensor:
+    """[n_layers, 256, B·⌈L/128⌉] per-workgroup row sums of dg, one slab per layer (written by fst_wn_layer_bwd, every entry)."""
+    return torch.empty(n_layers, 256, B * ((L + 127) // 128), device=device, dtype=torch.float32)
+
+
 def wn_layer_bwd(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, img: Tensor, dg: Tensor, last: bool, n: int,
-                 want_row_sums: bool = False, sums_out: Optional[Tensor] = None) -> Optional[Tensor]:
+                 want_row_sums: bool = False, sums_out: Optional[Tensor] = None, part: Optional[Tensor] = None) -> Optional[Tensor]:
     """``want_row_sums``: also returns Σ_{b,t} dg[:, row, :] ([2n]) — the in_layer / cond_layer bias gradient — from per-workgroup
-    partials the kernel leaves behind (no extra pass over dg)."""
+    partials the kernel leaves behind (no extra pass over dg).  ``part`` (a [256, B·⌈L/128⌉] slab of ``wn_bwd_partials``): the
+    partials are left there and NOT reduced here — the caller adds the slabs of all layers with one launch."""
     lib = _lib.load()
     B, _, L = d_out.shape
-    part = torch.empty(256, B * ((L + 127) // 128), device=dg.device, dtype=torch.float32) if want_row_sums else None
+    deferred = part is not None
+    if part is None and want_row_sums:
+        part = torch.empty(256, B * ((L + 127) // 128), device=dg.device, dtype=torch.float32)
     numel = _same_numel(d_out, d_a)
     for t in (ts, dg):
         if t.numel() != 2 * numel or not t.is_contiguous():
             raise ValueError("wn_layer_bwd: ts / dg must be contiguous [B, 2n, L]")
+    if part is not None and (part.shape != (256, B * ((L + 127) // 128)) or not part.is_contiguous()):
+        raise ValueError(f"wn_layer_bwd: partial-sum slab of shape {tuple(part.shape)}")
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     check(lib.fst_wn_layer_bwd(ptr(d_a), ptr(d_out), ptr(ts), ptr(img), img.numel() * 4, ptr(dg), ptr(part),
                                0 if part is None else part.size(1), int(last), B, L, n, numel, stream_ptr()), "fst_wn_layer_bwd")
     if t0 is not None:
         k = n if last else 2 * n
         KERNEL_TIMER.end("wn_layer_bwd_kernel", t0, 2.0 * B * L * n * k, 4.0 * B * L * (k + 4 * n))
-    if part is None:
+    if part is None or deferred:
         return None
     if sums_out is not None:
         return torch.sum(part[: 2 * n], dim=1, out=sums_out)
@@ -831,18 +842,28 @@ def wn_dgrad_ok(n: int, h: int, dil: int) -> bool:
     return bool(_lib.load().fst_wn_dgrad_fits(n, h, dil))
 
 
+def wn_dgrad_partials(n_layers: int, B: int, L: int, device) -> Tensor:
+    """[n_layers, 128, B·⌈L/512⌉] per-workgroup row sums of d_a, one slab per layer (written by fst_wn_layer_dgrad)."""
+    return torch.empty(n_layers, 128, B * ((L + WN_DGRAD_TILE - 1) // WN_DGRAD_TILE), device=device, dtype=torch.float32)
+
+
 def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor, n: int, h: int, dil: int,
-                   want_row_sums: bool = False, sums_out: Optional[Tensor] = None):
+                   want_row_sums: bool = False, sums_out: Optional[Tensor] = None, part: Optional[Tensor] = None):
     """returns d_a_new = d_a + W_inᵀ (*) dg;  d_u0 += W_condᵀ·dg  — one launch (csrc/wn_fused.hip).
     ``want_row_sums``: returns (d_a_new, Σ_{b,t} d_a_new[:, row, :]) — the residual half of the next res_skip bias gradient
-    (reduced into ``sums_out`` [n] when given)."""
+    (reduced into ``sums_out`` [n] when given).  ``part`` (a [128, B·⌈L/512⌉] slab of ``wn_dgrad_partials``): the partials are
+    left there, not reduced (returns (d_a_new, None)): the caller adds the slabs of all layers with one launch."""
     lib = _lib.load()
     B, _, L = dg.shape
-    part = torch.empty(128, B * ((L + WN_DGRAD_TILE - 1) // WN_DGRAD_TILE), device=dg.device, dtype=torch.float32) if want_row_sums else None
+    deferred = part is not None
+    if part is None and want_row_sums:
+        part = torch.empty(128, B * ((L + WN_DGRAD_TILE - 1) // WN_DGRAD_TILE), device=dg.device, dtype=torch.float32)
     d_a_new = torch.empty(B, n, L, device=dg.device, dtype=torch.float32)
     numel = _same_numel(d_a_new, d_a)
     if dg.numel() != 2 * numel or not dg.is_contiguous() or not d_u0.is_contiguous():
         raise ValueError("wn_layer_dgrad: dg must be contiguous [B, 2n, L], d_u0 contiguous [B, h, L]")
+    if part is not None and (part.shape != (128, B * ((L + WN_DGRAD_TILE - 1) // WN_DGRAD_TILE)) or not part.is_contiguous()):
+        raise ValueError(f"wn_layer_dgrad: partial-sum slab of shape {tuple(part.shape)}")
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     check(lib.fst_wn_layer_dgrad(ptr(dg), ptr(img), img.numel() * 4, ptr(d_a), ptr(d_a_new), ptr(d_u0), ptr(part),
                                  0 if part is None else part.size(1), B, L, n, h, dil, numel, d_u0.numel(), stream_ptr()),
@@ -850,8 +871,10 @@ def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor,
     if t0 is not None:
         KERNEL_TIMER.end("wn_layer_dgrad_kernel", t0, 2.0 * B * L * 2 * n * (3 * n + h),
                          4.0 * B * L * (2 * n + (n if d_a is not None else 0) + n + 2 * h))
-    if not want_row_sums:
+    if part is None:
         return d_a_new
+    if deferred:
+        return d_a_new, None
     if sums_out is not None:
         return d_a_new, torch.sum(part[:n], dim=1, out=sums_out)
     return d_a_new, part.sum(dim=1)[:n]
@@ -934,9 +957,11 @@ class WNFn(torch.autograd.Function):
         start_w, cond_w, end_w = weights[0], weights[2], weights[4]
         in_w, rs_w = weights[6: 6 + nl], weights[6 + 2 * nl: 6 + 3 * nl]
         need_w = ctx.needs_input_grad[2] and _want_weight_grad()
-        # every gradient is written into its segment of one flat tensor (zero-filled once: atomically accumulated row sums
-        # and plans that skip dead taps rely on it)
-        d_flat = torch.zeros_like(flat) if need_w else None
+        # every gradient is written into its segment of one flat tensor; every segment is written in full (all WN convs have
+        # dense plans, the bias sums are stored, not accumulated), so the tensor needs no zero fill
+        d_flat = torch.empty_like(flat) if need_w else None
+        if need_w and os.environ.get("FST_DEBUG_POISON") == "1":          # tests: an unwritten element shows up as NaN
+            d_flat.fill_(float("nan"))
         dw = S.unflatten(d_flat) if need_w else [None] * len(S.shapes)
         g_start_w, g_start_b, g_cond_w, g_cond_b, g_end_w, g_end_b = dw[:6]
         g_in_w, g_in_b = dw[6: 6 + nl], dw[6 + nl: 6 + 2 * nl]
@@ -962,10 +987,15 @@ class WNFn(torch.autograd.Function):
             o0 = S.offsets[6 + 3 * nl]
             d_rs_b_all = d_flat[o0: o0 + (nl - 1) * 2 * n].view(nl - 1, 2 * n)
             d_rs_b_all[:, n:] = d_out_sum
+        fused_bwd = ctx.fused and os.environ.get("FST_WN_BWD", "fused") == "fused"          # diagnostics: =unfused
+        fused_dg = [ctx.fused and wn_dgrad_ok(n, h, 2 ** i) and os.environ.get("FST_WN_DGRAD", "fused") == "fused" for i in range(nl)]
+        # bias-gradient row sums: every fused launch leaves per-workgroup partials in its slab; ONE reduction per kind adds the
+        # slabs of all layers straight into the flat gradient's segments (instead of one reduction launch per layer and kind)
+        part_b = wn_bwd_partials(nl, B, L, dev) if (need_w and fused_bwd) else None
+        part_d = wn_dgrad_partials(nl, B, L, dev) if (need_w and all(fused_dg)) else None
         for i in reversed(range(nl)):
             last = i == nl - 1
             # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
-            fused_bwd = ctx.fused and os.environ.get("FST_WN_BWD", "fused") == "fused"      # diagnostics: =unfused
             dacts = None if fused_bwd else torch.empty(B, n, L, device=dev, dtype=torch.float32)
             if fused_bwd:
                 pass
@@ -989,28 +1019,29 @@ class WNFn(torch.autograd.Function):
                     S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul, out0=g_rs_w[i])      # (its bias gradient is d_out_sum, in place)
                 else:
                     S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul, out0=g_rs_w[i])
-                    if d_a_sum is None:                   # not left behind by a fused data-gradient launch: one pass over d_a
+                    if part_d is None and d_a_sum is None:   # not left behind by a fused data-gradient launch: one pass over d_a
                         row_sum(d_a, out=d_rs_b_all[i, :n])
             # ---- through the gate
             dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
             dg_sum = None
             if fused_bwd:
                 dg_sum = wn_layer_bwd(None if last else d_a, d_out, ts_list[i], wn_pack_bwd(rs_w[i], n, last), dg, last, n,
-                                      want_row_sums=need_w, sums_out=g_in_b[i])
+                                      want_row_sums=need_w, sums_out=g_in_b[i], part=None if part_b is None else part_b[i])
             else:
                 check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]),
                                        stream_ptr()), "fst_gate_bwd")
             if need_w:
                 # in_layer weights and the layer's rows of the stacked cond_layer weights, unpacked in place
                 S.ins[i].grad_w(a_list[i], u0, dg, out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])
-                if dg_sum is None:                        # fused: reduced inside the backward kernel, straight into the segment
+                if dg_sum is None and part_b is None:     # fused: partials left by the backward kernel, reduced below
                     row_sum(dg, out=g_in_b[i])
             # ---- into the layer input (residual path + dilated conv) and into the conditioning input
-            if ctx.fused and wn_dgrad_ok(n, h, 2 ** i) and os.environ.get("FST_WN_DGRAD", "fused") == "fused":
+            if fused_dg[i]:
                 img_d = wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h)
                 if need_w:
                     d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i, want_row_sums=True,
-                                                  sums_out=d_rs_b_all[i - 1, :n] if i >= 1 else g_start_b)
+                                                  sums_out=d_rs_b_all[i - 1, :n] if i >= 1 else g_start_b,
+                                                  part=None if part_d is None else part_d[i])
                 else:
                     d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i), None
             else:
@@ -1018,7 +1049,17 @@ class WNFn(torch.autograd.Function):
         S.start.grad_x0(d_a, start_w, out=d_u0, flags=EPI_ACC1)
         if need_w:
             S.start.grad_w(u0, None, d_a, out0=g_start_w)
-            if d_a_sum is None:
+            if part_b is not None:
+                # in_layer biases of all layers = consecutive segments: one [nl, 2n] reduction
+                o0 = S.offsets[6 + nl]
+                torch.sum(part_b[:, : 2 * n, :], dim=2, out=d_flat[o0: o0 + nl * 2 * n].view(nl, 2 * n))
+            if part_d is not None:
+                # Σ d_a entering layer i (left by the data-gradient launch of layer i) = residual half of res_skip bias i−1, and
+                # the start conv's bias gradient for i = 0
+                if nl > 1:
+                    torch.sum(part_d[1:, :n, :], dim=2, out=d_rs_b_all[:, :n])
+                torch.sum(part_d[0, :n, :], dim=1, out=g_start_b)
+            elif d_a_sum is None:
                 row_sum(d_a, out=g_start_b)
             # cond_layer bias = the in_layer biases, stacked (consecutive segments: one copy)
             o0 = S.offsets[6 + nl]

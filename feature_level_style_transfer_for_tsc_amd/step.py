@@ -452,8 +452,9 @@ class JointTrainer:
                 it = iter(torch.split(flat, [g.numel() for gs in g_t + g_s for g in gs]))
                 g_t = [[next(it).view_as(g) for g in gs] for gs in g_t]
                 g_s = [[next(it).view_as(g) for g in gs] for gs in g_s]
-            base_t = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_t])
-            base_s = torch.stack([torch.stack([torch.norm(g) for g in gs]).sum() for gs in g_s])
+            # Σ_θ ‖∂L_i/∂θ‖₂ per loss (:685-690): all 5 × 12 norms as ONE multi-tensor launch (60 separate reductions before)
+            norms = torch.stack(torch._foreach_norm([g for gs in g_t + g_s for g in gs])).view(len(g_t) + len(g_s), -1).sum(dim=1)
+            base_t, base_s = norms[: len(g_t)], norms[len(g_t):]
         report = {k: v.detach() for k, v in L.items()}
         report.update({k: v.detach() for k, v in aux.items()})
         # scalars that must be identical on every rank: loss values and gradient-norm bases (10 floats)

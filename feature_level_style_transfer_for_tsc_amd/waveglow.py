@@ -28,6 +28,7 @@ class Invertible1x1Conv(nn.Module):
             W[:, 0] = -1 * W[:, 0]
         self.conv.weight.data = W.contiguous().view(c, c, 1)
         self.spec = ops.ConvSpec(c, c)
+        self._logdet_cache = None
 
     def forward(self, z: torch.Tensor, reverse: bool = False):
         batch_size, _, n_of_groups = z.size()
@@ -36,7 +37,16 @@ class Invertible1x1Conv(nn.Module):
                 self.W_inverse = self.conv.weight.detach().squeeze().float().inverse()[..., None].contiguous()
             return ops.conv1d(self.spec, z.contiguous(), self.W_inverse, None)
         W = self.conv.weight
-        log_det_W = batch_size * n_of_groups * torch.logdet(W.squeeze())
+        # inside WaveGlow.shared_fold() (one train step: W is the same for both forward passes) logdet(W) — an LU factorisation
+        # forward, a triangular solve backward, ~20 small launches — is taken once and its autograd node shared
+        cache = self._logdet_cache
+        if cache is not None and cache[0] is not None:
+            logdet = cache[0]
+        else:
+            logdet = torch.logdet(W.squeeze())
+            if cache is not None:
+                cache[0] = logdet
+        log_det_W = batch_size * n_of_groups * logdet
         return ops.conv1d(self.spec, z.contiguous(), W, None), log_det_W
 
 
@@ -112,11 +122,15 @@ class WaveGlow(nn.Module):
         def __enter__(self):
             for wn in self.wg.WN:
                 wn._fold_cache = [None]
+            for c in self.wg.convinv:
+                c._logdet_cache = [None]
             return self
 
         def __exit__(self, *exc):
             for wn in self.wg.WN:
                 wn._fold_cache = None
+            for c in self.wg.convinv:
+                c._logdet_cache = None
             return False
 
     def shared_fold(self):

@@ -139,12 +139,14 @@ int fst_row_sum(const float* x, int64_t x_bs, int B, int C, int L, float* out, v
  * from the tensors it holds — NOT recomputed from B, C, L.  The launcher refuses B*C*L != numel before launching, so a
  * batch argument that does not describe the buffers (the cause of round 1's GPU memory fault: the all-rank batch
  * passed as the launch batch of fst_bn_bwd_apply) is an error return, never an out-of-bounds walk. */
-/* Batch moments as partials: part[c][slot] = (count, mean, M2 = Σ(x − mean)²) of the samples workgroup `slot` of channel c
- * walked — FST_BN_SLOTS slots per channel, every one written (no zero fill by the caller, no atomics).  Merged with Chan's
- * formula, never as Σx² − (Σx)²/N: a channel of the univariate extractor's 1x1 shortcut has |mean|/std in the hundreds. */
+/* Batch moments as partials: part[c][slot] = (count, k, Σ(x − k), Σ(x − k)²) of the samples workgroup `slot` of channel c
+ * walked, shifted by k = y[0][c][0] — FST_BN_SLOTS slots per channel, every one written (no zero fill by the caller, no
+ * atomics).  Never Σx² − (Σx)²/N of the raw values: a channel of the univariate extractor's 1x1 shortcut has |mean|/std in
+ * the hundreds, where that form has no correct digit of the variance in fp32. */
 #define FST_BN_SLOTS 16
-int fst_bn_stats(const float* y, int B, int C, int L, float* part /* [C][FST_BN_SLOTS][3], written */, int64_t numel, void* stream);
-/* Merges the n_slots partials of every channel in slot order (double precision) into the batch mean / biased variance, updates
+int fst_bn_stats(const float* y, int B, int C, int L, float* part /* [C][FST_BN_SLOTS][4], written */, int64_t numel, void* stream);
+/* Turns every slot into (count, mean, M2) and merges the n_slots of a channel in slot order with Chan's formula (double
+ * precision) into the batch mean / biased variance, updates
  * the running statistics (unbiased variance) and writes stats.  n_slots = FST_BN_SLOTS, or ranks·FST_BN_SLOTS in global-batch
  * data parallelism (SyncBN) after the caller gathered every rank's partials as part[c][rank·FST_BN_SLOTS + slot].
  * train = 0: part may be NULL; stats from the running statistics. */

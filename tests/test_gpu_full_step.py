@@ -50,8 +50,7 @@ def _head_unit_branches(record=None, impose=None, flips=None):
     whose pre-activation is within rounding distance of zero takes either branch depending on the last bits, and one such
     unit at B = 3 moves every gradient upstream of it by percent.  The forward VALUE is unaffected (the pre-activation is
     ~0 either way), so the oracle is stepped on the piece the device run was on and then compared tightly.  The ReLUs
-    fused into the BatchNorm kernels (the omni-scale convolutions) cannot be recorded and are left alone: one element
-    there is one of B·C·L.
+    fused into the BatchNorm kernels (the omni-scale convolutions) are recorded from the launches' outputs (out > 0).
     Imposing is BOUNDED: wherever the imposed branch differs from the one the oracle's own pre-activation selects, that
     pre-activation must be within FLIP_BOUND of zero relative to the layer's largest — a unit the device got wrong by more
     than rounding fails here instead of dragging the oracle along.  ``flips`` (a list) receives (layer index, units
@@ -72,7 +71,9 @@ def _head_unit_branches(record=None, impose=None, flips=None):
                                          f"|x|/max|x| up to {worst:.2e} — not a rounding-level disagreement")
 
     def synced(x):
-        return x.dim() == 2 or record is not None or inside[0] > 0     # the device side calls F.relu only in these layers
+        # record mode sees only the layers that call F.relu on the device (heads, dimension unification); impose mode consumes one
+        # recorded mask per ReLU of the oracle — the convolutional ones included, recorded from the fused BatchNorm+ReLU launches
+        return True
 
     def relu(x, inplace=False):
         if not synced(x):
@@ -103,15 +104,33 @@ def _head_unit_branches(record=None, impose=None, flips=None):
         finally:
             inside[0] -= 1
 
+    from feature_level_style_transfer_for_tsc_amd import ops as _ops
     F.relu, F.leaky_relu = relu, leaky
     if impose is not None:
         R.dimension_unification = dimunif
+    if record is not None:
+        # the omni-scale layers' ReLUs run inside the BatchNorm kernels: record the branch from the launch's output
+        bn_act, bn_join = _ops.BNActFn.apply, _ops.BNAddBNReluFn.apply
+
+        def bn_act_rec(*a):
+            out = bn_act(*a)
+            if a[6]:                                               # relu flag of BNActFn.forward
+                record.append((out.detach() > 0).cpu())
+            return out
+
+        def bn_join_rec(*a):
+            out = bn_join(*a)
+            record.append((out.detach() > 0).cpu())
+            return out
+        _ops.BNActFn.apply, _ops.BNAddBNReluFn.apply = bn_act_rec, bn_join_rec
     try:
         yield
         if it is not None:
             assert next(it, None) is None, "the oracle evaluated fewer synchronised layers than the device run"
     finally:
         F.relu, F.leaky_relu, R.dimension_unification = relu0, leaky0, dimunif0
+        if record is not None:
+            del _ops.BNActFn.apply, _ops.BNAddBNReluFn.apply       # back to the inherited Function.apply
 
 
 def _step_both(js, tr, batch, ts):

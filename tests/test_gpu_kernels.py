@@ -375,7 +375,7 @@ def test_batch_norm_global_batch_arguments_stay_inside_their_buffers():
     (ybuf, y), (dybuf, dy), (dxbuf, dx) = padded(y_h), padded(dy_h), padded()
     gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
     rmean, rvar = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-    part = torch.full((C, ops.BN_SLOTS, 3), CANARY, device=DEV)      # every slot must be written by the kernel (no zero fill)
+    part = torch.full((C, ops.BN_SLOTS, 4), CANARY, device=DEV)      # every slot must be written by the kernel (no zero fill)
     _lib.check(lib.fst_bn_stats(y.data_ptr(), B, C, L, part.data_ptr(), n, _lib.stream_ptr()), "bn_stats")
     assert float(part[:, :, 0].sum(dim=1).min()) == B * L and float(part[:, :, 0].sum(dim=1).max()) == B * L
     B_total = 3 * B

@@ -37,11 +37,17 @@ for e in prof.events():
     if not ks:
         continue
     n_kernels += len(ks)
-    where = "autograd / optimizer / other"
+    where = None
     for fr in (e.stack or []):
         if "feature_level_style_transfer_for_tsc_amd" in fr:
             where = fr.split("feature_level_style_transfer_for_tsc_amd/")[-1]
             break
+    if where is None:                        # no Python stack on this event: the chain of enclosing ops / autograd nodes instead
+        chain, q = [], e.cpu_parent
+        while q is not None and len(chain) < 4:
+            chain.append(q.name)
+            q = q.cpu_parent
+        where = " < ".join(chain) if chain else "(top level)"
     key = (e.name, where)
     agg[key][0] += len(ks)
     agg[key][1] += sum(k.duration for k in ks)
@@ -50,5 +56,5 @@ tot_n = tot_us = 0
 for (name, where), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     tot_n += n
     tot_us += us
-    print(f"{n:5d} launches {us:9.1f} us  {name:40s} {where}")
+    print(f"{n:5d} launches {us:9.1f} us  {name:36s} {where}")
 print(f"total {tot_n} launches, {tot_us / 1e3:.2f} ms of device time")
