@@ -51,9 +51,12 @@ _SIGNATURES = {
     "fst_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_coupling_sum_slots": (c_int64, [c_int, c_int, c_int]),
     "fst_coupling_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, _P, c_void_p]),
-    "fst_coupling_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_coupling_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_coupling_inv_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_coupling_inv_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_wn_fold_fwd": (c_int, [_P, c_int, _P, _P, c_void_p]),
+    "fst_wn_fold_bwd": (c_int, [_P, c_int, _P, _P, _P, c_void_p]),
+    "fst_logdet_inv": (c_int, [_P, c_int, _P, _P, c_void_p]),
     "fst_wn_image_bytes": (c_int64, [c_int, c_int]),
     "fst_wn_pack": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, c_void_p]),
     "fst_wn_layer_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -580,15 +580,15 @@ extern "C" int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, i
 }
 
 // forward-coupling backward.  dxn: grad of xn (2h ch, may be null = 0); dlogs: extra grad flowing into log_s (may be null);
-// gsums (may be null): DEVICE scalars (d/dΣlog_s, d/dΣxn²) of the fused loss reductions:  dxn_eff = dxn + 2·gsums[1]·xn
-//   du0 = dxn0 ; du1 = dxn1*exp(s) ; db = dxn1 ; ds = dxn1*u1*exp(s) + dlogs + gsums[0]
+// g_ls, g_sq (each may be null): DEVICE scalars d/dΣlog_s and d/dΣxn² of the fused loss reductions:  dxn_eff = dxn + 2·g_sq·xn
+//   du0 = dxn0 ; du1 = dxn1*exp(s) ; db = dxn1 ; ds = dxn1*u1*exp(s) + dlogs + g_ls
 __global__ __launch_bounds__(256) void coupling_bwd_kernel(const float* u, const float* o, const float* dxn,
-                                                           const float* dlogs, const float* gsums, float* du, float* d_o,
-                                                           int h, int L) {
+                                                           const float* dlogs, const float* g_ls_p, const float* g_sq_p,
+                                                           float* du, float* d_o, int h, int L) {
   const int b = blockIdx.y;
   const long long half = (long long)h * L;
   const long long off = (long long)b * 2 * half;
-  const float g_ls = gsums ? gsums[0] : 0.f, g_sq2 = gsums ? 2.f * gsums[1] : 0.f;
+  const float g_ls = g_ls_p ? g_ls_p[0] : 0.f, g_sq2 = g_sq_p ? 2.f * g_sq_p[0] : 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < half; i += (long long)gridDim.x * 256) {
     const float es = expf(o[off + half + i]);
     const float u0 = u[off + i], u1 = u[off + half + i];
@@ -604,14 +604,14 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(const float* u, const
   }
 }
 
-extern "C" int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, const float* gsums,
-                                float* du, float* d_o, int B, int h, int L, int64_t numel, void* stream) {
-  FST_REQUIRE(u && o && (dxn || gsums) && du && d_o && B > 0 && h > 0 && L > 0, "fst_coupling_bwd: bad arguments");
+extern "C" int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, const float* g_ls,
+                                const float* g_sq, float* du, float* d_o, int B, int h, int L, int64_t numel, void* stream) {
+  FST_REQUIRE(u && o && (dxn || g_ls || g_sq) && du && d_o && B > 0 && h > 0 && L > 0, "fst_coupling_bwd: bad arguments");
   FST_REQUIRE_EXTENT("fst_coupling_bwd", B, 2 * h, L, numel);
   long long blocks = ((long long)h * L + 255) / 256;
   if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, dxn, dlogs, gsums, du,
-                     d_o, h, L);
+  hipLaunchKernelGGL(coupling_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, u, o, dxn, dlogs, g_ls, g_sq,
+                     du, d_o, h, L);
   FST_LAUNCH_CHECK();
   return 0;
 }
@@ -677,6 +677,173 @@ extern "C" int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_
   if (blocks > 64) blocks = 64;
   hipLaunchKernelGGL(add_slices_kernel, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, dst, (long long)dst_bs, a,
                      (long long)a_bs, b, (long long)b_bs, C, L);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- log|det W| and W^{-T} of the invertible 1x1 conv
+// torch.logdet(W) (Simplified_NF_WaveGlow.py:40) is an LU factorisation plus ~17 tiny launches forward and two triangular
+// solves plus ~10 launches backward — for a 50x50 matrix, three times per step, all on the critical path of the captured step.
+// One workgroup does both here: in-place Gauss-Jordan inversion with partial pivoting, in double precision in LDS; the pivots
+// give log|det| and its sign, the inverse (transposed) is the gradient d log|det W| / dW the backward needs.
+//   out[0] = log|det W| with torch.logdet's conventions: NaN for a negative determinant, -inf for a singular matrix
+//   out[1] = sign of the determinant (+1, -1, 0)
+__global__ __launch_bounds__(256) void logdet_inv_kernel(const float* W, int n, float* out, float* inv_t) {
+  extern __shared__ __attribute__((aligned(16))) double sa[];       // [n][n]
+  __shared__ int piv_row[256];
+  __shared__ double red_v[256];
+  __shared__ int red_i[256];
+  __shared__ double s_logabs;
+  __shared__ int s_sign, s_p;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n * n; i += 256) sa[i] = (double)W[i];
+  if (tid == 0) { s_logabs = 0.0; s_sign = 1; }
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    // pivot: largest |a[i][k]|, i >= k (lowest index on ties: deterministic)
+    double best = -1.0; int bi = k;
+    for (int i = k + tid; i < n; i += 256) {
+      const double v = fabs(sa[i * n + k]);
+      if (v > best) { best = v; bi = i; }
+    }
+    red_v[tid] = best; red_i[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        const double v2 = red_v[tid + s]; const int i2 = red_i[tid + s];
+        if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int p = red_i[0];
+      s_p = p; piv_row[k] = p;
+      const double pv = sa[p * n + k];
+      if (pv == 0.0) s_sign = 0;
+      else {
+        s_logabs += log(fabs(pv));
+        if ((pv < 0.0) != (p != k)) s_sign = -s_sign;          // a negative pivot and a row swap each flip the sign
+      }
+    }
+    __syncthreads();
+    if (s_sign == 0) break;                                       // singular (uniform: read from LDS after the barrier)
+    const int p = s_p;
+    if (p != k) {
+      for (int j = tid; j < n; j += 256) { const double t = sa[k * n + j]; sa[k * n + j] = sa[p * n + j]; sa[p * n + j] = t; }
+      __syncthreads();
+    }
+    const double rp = 1.0 / sa[k * n + k];
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) sa[k * n + j] = (j == k ? 1.0 : sa[k * n + j]) * rp;
+    __syncthreads();
+    // eliminate column k from every other row; the column itself becomes -f * (1/pivot) (in-place inverse bookkeeping)
+    for (int e = tid; e < n * n; e += 256) {
+      const int i = e / n, j = e - i * n;
+      if (i == k || j == k) continue;
+      sa[e] -= sa[i * n + k] * sa[k * n + j];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+      if (i != k) sa[i * n + k] = -sa[i * n + k] * rp;
+    __syncthreads();
+  }
+  const int sign = s_sign;
+  if (sign != 0) {
+    // undo the row swaps as column swaps, last first: A^{-1} = (P·A)^{-1}·P
+    for (int k = n - 1; k >= 0; --k) {
+      const int p = piv_row[k];
+      if (p != k) {
+        for (int i = tid; i < n; i += 256) { const double t = sa[i * n + k]; sa[i * n + k] = sa[i * n + p]; sa[i * n + p] = t; }
+        __syncthreads();
+      }
+    }
+  }
+  for (int e = tid; e < n * n; e += 256) {
+    const int i = e / n, j = e - i * n;
+    inv_t[e] = sign != 0 ? (float)sa[j * n + i] : __builtin_nanf("");
+  }
+  if (tid == 0) {
+    out[0] = sign > 0 ? (float)s_logabs : (sign < 0 ? __builtin_nanf("") : -__builtin_inff());
+    out[1] = (float)sign;
+  }
+}
+
+extern "C" int fst_logdet_inv(const float* W, int n, float* out, float* inv_t, void* stream) {
+  FST_REQUIRE(W && out && inv_t && n > 0 && n <= 128, "fst_logdet_inv: needs 0 < n <= 128 (one workgroup holds the matrix in LDS as doubles); n=%d", n);
+  const size_t lds = (size_t)n * n * sizeof(double);
+  if (lds > 48 * 1024)
+    if (int rc = fst_allow_full_lds((const void*)logdet_inv_kernel, "fst_logdet_inv")) return rc;
+  hipLaunchKernelGGL(logdet_inv_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, W, n, out, inv_t);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- weight-norm fold of a whole WN into its flat weight tensor
+// The reference wraps 18 convs of every WN in old-style weight_norm (Simplified_NF_WaveGlow.py:69-99): w = g·v/‖v‖ per output
+// channel, recomputed every forward — 18 launches forward and 18 backward per WN as stock ops, plus the concatenation into the
+// flat tensor the fused kernels read.  Here ONE launch per WN and direction walks a row table: row r = one output channel of one
+// conv (or one plain-copy segment: biases, the un-normed end conv), a wave per row.
+//   table[r] = { v_row (pointer), g (pointer to the row's scalar, 0 = plain copy), dst (element offset into flat), len,
+//                dv (element offset into the gradient buffer), dg (element offset of the row's g gradient) }   (6 x int64)
+struct WnFoldRow { long long v, g, dst, len, dv, dg; };
+
+__global__ __launch_bounds__(256) void wn_fold_fwd_kernel(const WnFoldRow* __restrict__ table, int n_rows, float* flat, float* norms) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n_rows) return;
+  const WnFoldRow row = table[r];
+  const float* v = reinterpret_cast<const float*>(row.v);
+  const int len = (int)row.len;
+  float* dst = flat + row.dst;
+  if (row.g == 0) {
+    for (int j = lane; j < len; j += 64) dst[j] = v[j];
+    return;
+  }
+  float ss = 0.f;
+  for (int j = lane; j < len; j += 64) ss += v[j] * v[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float norm = sqrtf(ss);
+  const float scale = *reinterpret_cast<const float*>(row.g) / norm;
+  for (int j = lane; j < len; j += 64) dst[j] = v[j] * scale;
+  if (lane == 0) norms[r] = norm;
+}
+
+// dv = (g/‖v‖)·(dw − v·(dw·v)/‖v‖²),  dg = (dw·v)/‖v‖   (torch's weight_norm backward); copy rows: dv = dw
+__global__ __launch_bounds__(256) void wn_fold_bwd_kernel(const WnFoldRow* __restrict__ table, int n_rows, const float* d_flat,
+                                                          const float* norms, float* dpar) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n_rows) return;
+  const WnFoldRow row = table[r];
+  const float* v = reinterpret_cast<const float*>(row.v);
+  const int len = (int)row.len;
+  const float* dw = d_flat + row.dst;
+  float* dv = dpar + row.dv;
+  if (row.g == 0) {
+    for (int j = lane; j < len; j += 64) dv[j] = dw[j];
+    return;
+  }
+  float dot = 0.f;
+  for (int j = lane; j < len; j += 64) dot += dw[j] * v[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  const float norm = norms[r], g = *reinterpret_cast<const float*>(row.g);
+  const float a = g / norm, b = dot / (norm * norm);
+  for (int j = lane; j < len; j += 64) dv[j] = a * (dw[j] - v[j] * b);
+  if (lane == 0) dpar[row.dg] = dot / norm;
+}
+
+extern "C" int fst_wn_fold_fwd(const int64_t* table_dev, int n_rows, float* flat, float* norms, void* stream) {
+  FST_REQUIRE(table_dev && flat && norms && n_rows > 0, "fst_wn_fold_fwd: bad arguments");
+  hipLaunchKernelGGL(wn_fold_fwd_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const WnFoldRow*>(table_dev), n_rows, flat, norms);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fst_wn_fold_bwd(const int64_t* table_dev, int n_rows, const float* d_flat, const float* norms, float* dpar,
+                               void* stream) {
+  FST_REQUIRE(table_dev && d_flat && norms && dpar && n_rows > 0, "fst_wn_fold_bwd: bad arguments");
+  hipLaunchKernelGGL(wn_fold_bwd_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const WnFoldRow*>(table_dev), n_rows, d_flat, norms, dpar);
   FST_LAUNCH_CHECK();
   return 0;
 }

@@ -953,7 +953,8 @@ struct WnDgradParams {
   const char* img;
   const float* d_a;     // [B][n][L] residual cotangent, or null
   float* d_a_new;       // [B][n][L]
-  float* d_u0;          // [B][h][L], accumulated
+  float* d_u0;          // [B][h][L] with batch stride d_u0_bs (a channel slice of a wider tensor passes as it is), accumulated
+  long long d_u0_bs;
   float* row_sums;      // optional [128][n_wg]: per-workgroup Σ_t d_a_new[row] — the res rows of the next res_skip bias gradient
   int B, L, n, h, dil, CHK, tiles_per_seq, n_wg;
   int nblkw;            // 32-sample column blocks of the window
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
     for (int mb = 0; mb < 5; ++mb)
 #pragma unroll
       for (int cb = 0; cb < DG_NCB; ++cb) {
-        const float* src = mb < 4 ? (p.d_a ? p.d_a + ((long long)b * n + mb * 32) * L : nullptr) : p.d_u0 + (long long)b * p.h * L;
+        const float* src = mb < 4 ? (p.d_a ? p.d_a + ((long long)b * n + mb * 32) * L : nullptr) : p.d_u0 + (long long)b * p.d_u0_bs;
         const int rows = (DG_EXP & 32) ? 0 : (mb < 4 ? (p.d_a ? n - mb * 32 : 0) : p.h);
         wn_acc_load(acc[mb][cb], src, rows, L, t0 + wave_n0 + 32 * cb, lane);
       }
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
 #pragma unroll
     for (int k = 0; k < 5 * DG_NCB; ++k) {
       const int i = k / DG_NCB, cb = k % DG_NCB, tcol = t0 + wave_n0 + 32 * cb;
-      float* dst = i < 4 ? p.d_a_new + ((long long)b * n + i * 32) * L : p.d_u0 + (long long)b * p.h * L;
+      float* dst = i < 4 ? p.d_a_new + ((long long)b * n + i * 32) * L : p.d_u0 + (long long)b * p.d_u0_bs;
       const int rows = i < 4 ? n - i * 32 : p.h;
       if (DG_EXP & 16) { if (acc[i][cb][0] == 12345.678f) dst[0] = 1.f; continue; }
       wn_acc_store(acc[i][cb], dst, (DG_EXP & 8) ? 0 : rows, L, tcol, lane);
@@ -1149,19 +1150,21 @@ extern "C" int fst_wn_dgrad_fits(int n, int h, int dil) {
 
 extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new,
                                   float* d_u0, float* row_sums, int64_t row_sums_rows, int B, int L, int n, int h, int dil,
-                                  int64_t numel_a, int64_t numel_u0, void* stream) {
+                                  int64_t numel_a, int64_t d_u0_bs, void* stream) {
   FST_REQUIRE(dg && image && d_a_new && d_u0, "fst_wn_layer_dgrad: null operand");
   FST_REQUIRE(B > 0 && L > 0 && n > 0 && n <= 128 && h > 0 && h <= 32 && dil > 0, "fst_wn_layer_dgrad: B=%d L=%d n=%d h=%d dil=%d", B, L,
               n, h, dil);
-  FST_REQUIRE((long long)B * n * L == (long long)numel_a && (long long)B * h * L == (long long)numel_u0,
-              "fst_wn_layer_dgrad: B*n*L / B*h*L do not match the element counts %lld / %lld", (long long)numel_a, (long long)numel_u0);
+  FST_REQUIRE((long long)B * n * L == (long long)numel_a,
+              "fst_wn_layer_dgrad: B*n*L does not match the element count %lld of the [B][n][L] tensors", (long long)numel_a);
+  FST_REQUIRE(d_u0_bs >= (int64_t)h * L && d_u0_bs % 4 == 0,
+              "fst_wn_layer_dgrad: d_u0 batch stride %lld (needs >= h*L = %lld and a multiple of 4)", (long long)d_u0_bs, (long long)h * L);
   FST_REQUIRE(image_bytes == fst_wn_dgrad_image_bytes(n), "fst_wn_layer_dgrad: image is %lld bytes, expected %lld",
               (long long)image_bytes, (long long)fst_wn_dgrad_image_bytes(n));
   auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   FST_REQUIRE(L % 4 == 0 && al16(dg) && al16(image) && al16(d_a) && al16(d_a_new) && al16(d_u0),
               "fst_wn_layer_dgrad: needs L %% 4 == 0 and 16-byte aligned tensors (L=%d)", L);
   WnDgradParams p;
-  p.dg = dg; p.img = static_cast<const char*>(image); p.d_a = d_a; p.d_a_new = d_a_new; p.d_u0 = d_u0;
+  p.dg = dg; p.img = static_cast<const char*>(image); p.d_a = d_a; p.d_a_new = d_a_new; p.d_u0 = d_u0; p.d_u0_bs = d_u0_bs;
   p.row_sums = row_sums;
   p.B = B; p.L = L; p.n = n; p.h = h; p.dil = dil; p.CHK = (2 * n + 15) / 16;
   p.tiles_per_seq = (L + DG_TN - 1) / DG_TN;

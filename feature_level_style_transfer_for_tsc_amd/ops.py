@@ -714,6 +714,95 @@ class WNSpecs:
         return [flat[self.offsets[i]: self.offsets[i + 1]].view(sh) for i, sh in enumerate(self.shapes)]
 
 
+class WNFoldPlan:
+    """Row table of ``WNFoldFn`` for one WN: which parameter tensors (weight-normed (v, g) pairs and plain tensors, in
+    ``WNSpecs.shapes`` order) fill which segment of the flat weight tensor.  The device table holds the parameters' ADDRESSES: it is
+    rebuilt (one small host-to-device copy) only when a parameter's storage moves — never in a steady train loop, so a captured
+    hipGraph replays it as it is (optimisers update in place)."""
+
+    def __init__(self, specs: "WNSpecs", normed: Sequence[bool]):
+        assert len(normed) == len(specs.shapes)
+        self.specs, self.normed = specs, list(normed)
+        self._key, self._table = None, None
+        self.n_rows = sum(sh[0] if nm else 1 for sh, nm in zip(specs.shapes, normed))
+        # gradient buffer layout: the input tensors' gradients back to back, in input order (v, g per normed entry)
+        self.grad_offsets, off = [], 0
+        for sh, nm in zip(specs.shapes, normed):
+            numel = int(math.prod(sh))
+            self.grad_offsets.append(off)
+            off += numel
+            if nm:
+                self.grad_offsets.append(off)
+                off += sh[0]
+        self.grad_numel = off
+
+    def n_inputs(self) -> int:
+        return len(self.grad_offsets)
+
+    def table(self, tensors: Sequence[Tensor]) -> Tensor:
+        import numpy as np
+        key = tuple(t.data_ptr() for t in tensors) + (str(tensors[0].device),)
+        if key == self._key:
+            return self._table
+        rows, it, gi = [], iter(tensors), 0
+        for i, (sh, nm) in enumerate(zip(self.specs.shapes, self.normed)):
+            dst, numel = self.specs.offsets[i], int(math.prod(sh))
+            if nm:
+                v, g = next(it), next(it)
+                M, rowlen = sh[0], numel // sh[0]
+                assert v.is_contiguous() and g.is_contiguous() and tuple(v.shape) == tuple(sh) and g.numel() == M
+                m = np.arange(M, dtype=np.int64)
+                blk = np.stack([v.data_ptr() + 4 * rowlen * m, g.data_ptr() + 4 * m, dst + rowlen * m, np.full(M, rowlen, np.int64),
+                                self.grad_offsets[gi] + rowlen * m, self.grad_offsets[gi + 1] + m], axis=1)
+                gi += 2
+            else:
+                t = next(it)
+                assert t.is_contiguous() and t.numel() == numel
+                blk = np.array([[t.data_ptr(), 0, dst, numel, self.grad_offsets[gi], 0]], dtype=np.int64)
+                gi += 1
+            rows.append(blk)
+        tab = np.concatenate(rows, axis=0)
+        assert tab.shape == (self.n_rows, 6)
+        self._table = torch.from_numpy(tab).to(tensors[0].device)
+        self._key = key
+        return self._table
+
+
+class WNFoldFn(torch.autograd.Function):
+    """flat = the effective weights of one WN (``WNSpecs.shapes`` order) from its parameters: g·v/‖v‖ for the weight-normed convs
+    (Simplified_NF_WaveGlow.py:69-99, old-style weight_norm over dim 0), plain copies for the biases and the end conv — ONE launch
+    (fst_wn_fold_fwd) instead of 18 weight-norm launches and a concatenation; the backward (fst_wn_fold_bwd) is one launch too."""
+
+    @staticmethod
+    def forward(ctx, plan: WNFoldPlan, *tensors: Tensor):
+        lib = _lib.load()
+        assert len(tensors) == plan.n_inputs()
+        for t in tensors:
+            _lib.require_gpu_tensor(t, "WN parameter")
+        tab = plan.table(tensors)
+        dev = tensors[0].device
+        flat = torch.empty(plan.specs.flat_numel, device=dev, dtype=torch.float32)
+        norms = torch.empty(plan.n_rows, device=dev, dtype=torch.float32)
+        check(lib.fst_wn_fold_fwd(ptr(tab), plan.n_rows, ptr(flat), ptr(norms), stream_ptr()), "fst_wn_fold_fwd")
+        ctx.plan, ctx.tab = plan, tab
+        ctx.shapes = [tuple(t.shape) for t in tensors]
+        ctx.save_for_backward(norms)
+        return flat
+
+    @staticmethod
+    def backward(ctx, d_flat):
+        lib = _lib.load()
+        (norms,) = ctx.saved_tensors
+        plan: WNFoldPlan = ctx.plan
+        d_flat = d_flat.contiguous()
+        dpar = torch.empty(plan.grad_numel, device=d_flat.device, dtype=torch.float32)
+        check(lib.fst_wn_fold_bwd(ptr(ctx.tab), plan.n_rows, ptr(d_flat), ptr(norms), ptr(dpar), stream_ptr()), "fst_wn_fold_bwd")
+        grads = []
+        for off, sh in zip(plan.grad_offsets, ctx.shapes):
+            grads.append(dpar[off: off + int(math.prod(sh))].view(sh))
+        return (None, *grads)
+
+
 def wn_fused_ok(n: int, h: int, L: int, *tensors: Tensor, kernel: int = 3) -> bool:
     """Whether a WN layer takes the fused one-launch-per-layer kernels (csrc/wn_fused.hip): split-bf16 arithmetic,
     three taps (the kernels hard-code taps at 0 and ±dil; the reference's WN takes any kernel_size,
@@ -860,13 +949,16 @@ def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor,
         part = torch.empty(128, B * ((L + WN_DGRAD_TILE - 1) // WN_DGRAD_TILE), device=dg.device, dtype=torch.float32)
     d_a_new = torch.empty(B, n, L, device=dg.device, dtype=torch.float32)
     numel = _same_numel(d_a_new, d_a)
-    if dg.numel() != 2 * numel or not dg.is_contiguous() or not d_u0.is_contiguous():
-        raise ValueError("wn_layer_dgrad: dg must be contiguous [B, 2n, L], d_u0 contiguous [B, h, L]")
+    if dg.numel() != 2 * numel or not dg.is_contiguous():
+        raise ValueError("wn_layer_dgrad: dg must be contiguous [B, 2n, L]")
+    d_u0_bs, _ = _ncl(d_u0, "d_u0")
+    if tuple(d_u0.shape) != (B, h, L):
+        raise ValueError(f"wn_layer_dgrad: d_u0 must be [B, h, L] = {(B, h, L)}, got {tuple(d_u0.shape)}")
     if part is not None and (part.shape != (128, B * ((L + WN_DGRAD_TILE - 1) // WN_DGRAD_TILE)) or not part.is_contiguous()):
         raise ValueError(f"wn_layer_dgrad: partial-sum slab of shape {tuple(part.shape)}")
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     check(lib.fst_wn_layer_dgrad(ptr(dg), ptr(img), img.numel() * 4, ptr(d_a), ptr(d_a_new), ptr(d_u0), ptr(part),
-                                 0 if part is None else part.size(1), B, L, n, h, dil, numel, d_u0.numel(), stream_ptr()),
+                                 0 if part is None else part.size(1), B, L, n, h, dil, numel, d_u0_bs, stream_ptr()),
           "fst_wn_layer_dgrad")
     if t0 is not None:
         KERNEL_TIMER.end("wn_layer_dgrad_kernel", t0, 2.0 * B * L * 2 * n * (3 * n + h),
@@ -878,6 +970,177 @@ def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor,
     if sums_out is not None:
         return d_a_new, torch.sum(part[:n], dim=1, out=sums_out)
     return d_a_new, part.sum(dim=1)[:n]
+
+
+def _wn_forward(specs: WNSpecs, u0: Tensor, flat: Tensor):
+    """Forward of the WN stack (WNFn's docstring).  Returns (o, fused, the tensors ``_wn_backward`` needs)."""
+    lib = _lib.load()
+    S, nl = specs, specs.n_layers
+    flat = flat.contiguous()
+    weights = S.unflatten(flat)
+    start_w, start_b, cond_w, cond_b, end_w, end_b = weights[:6]
+    in_w, in_b = weights[6: 6 + nl], weights[6 + nl: 6 + 2 * nl]
+    rs_w, rs_b = weights[6 + 2 * nl: 6 + 3 * nl], weights[6 + 3 * nl: 6 + 4 * nl]
+    B, _, L = u0.shape
+    h, n = S.h, S.n
+    a = S.start.forward(u0, None, start_w, None, start_b)
+    a_list, ts_list, acts_list = [a], [], []
+    fused = wn_fused_ok(n, h, L, a, u0, kernel=S.kernel)
+    if fused:
+        # one launch per layer: dilated conv + cond rows → gate in registers → res_skip → residual / skip adds
+        out = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
+        cb = cond_b.view(nl, 2 * n)
+        for i in range(nl):
+            last = i == nl - 1
+            img = wn_pack_layer(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], in_b[i], cb[i], rs_w[i], rs_b[i], n, h, last)
+            ts = torch.empty(B, 2 * n, L, device=u0.device, dtype=torch.float32)
+            a_next = None if last else torch.empty_like(a)
+            # acts = t·s is not written: the res_skip weight gradient re-forms it from the saved halves while staging
+            wn_layer_fwd(a, u0, img, ts, None, a_next, out, i == 0, last, n, h, 2 ** i)
+            ts_list.append(ts)
+            if not last:
+                a = a_next
+                a_list.append(a)
+    else:
+        out = torch.zeros(B, n, L, device=u0.device, dtype=torch.float32)
+        bias_g = torch.stack(list(in_b)) + cond_b.view(nl, 2 * n)
+    for i in range(0 if fused else nl):
+        g = S.ins[i].forward(a, u0, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], bias_g[i])
+        acts = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
+        check(lib.fst_gate_fwd(ptr(g), ptr(acts), B, n, L, _gate_numel(acts, g), stream_ptr()), "fst_gate_fwd")
+        ts_list.append(g)
+        acts_list.append(acts)
+        if i < nl - 1:
+            a_next = torch.empty_like(a)
+            S.rs[i].forward(acts, None, rs_w[i], None, rs_b[i], y=a_next, res=a, y2=out, msplit=n, flags=EPI_ACC2)
+            a = a_next
+            a_list.append(a)
+        else:
+            S.rs[i].forward(acts, None, rs_w[i], None, rs_b[i], y=None, y2=out, msplit=0, flags=EPI_ACC2)
+    o = S.end.forward(out, None, end_w, None, end_b)
+    if fused:
+        acts_list = ts_list                                           # placeholders (same count) for the saved-tensor layout
+    return o, fused, (u0, out, *a_list, *ts_list, *acts_list, flat)
+
+
+def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: bool):
+    """Backward of the WN stack: the input gradient is ACCUMULATED into ``d_u0`` ([B, h, L], possibly a channel-slice view of
+    a wider tensor with an explicit batch stride); returns the flat weight gradient (None unless ``need_w``)."""
+    lib = _lib.load()
+    nl, h, n = S.n_layers, S.h, S.n
+    u0, out = sv[0], sv[1]
+    a_list, ts_list, acts_list = sv[2: 2 + nl], sv[2 + nl: 2 + 2 * nl], sv[2 + 2 * nl: 2 + 3 * nl]
+    flat = sv[2 + 3 * nl]
+    weights = S.unflatten(flat)
+    start_w, cond_w, end_w = weights[0], weights[2], weights[4]
+    in_w, rs_w = weights[6: 6 + nl], weights[6 + 2 * nl: 6 + 3 * nl]
+    # every gradient is written into its segment of one flat tensor; every segment is written in full (all WN convs have
+    # dense plans, the bias sums are stored, not accumulated), so the tensor needs no zero fill
+    d_flat = torch.empty_like(flat) if need_w else None
+    if need_w and os.environ.get("FST_DEBUG_POISON") == "1":          # tests: an unwritten element shows up as NaN
+        d_flat.fill_(float("nan"))
+    dw = S.unflatten(d_flat) if need_w else [None] * len(S.shapes)
+    g_start_w, g_start_b, g_cond_w, g_cond_b, g_end_w, g_end_b = dw[:6]
+    g_in_w, g_in_b = dw[6: 6 + nl], dw[6 + nl: 6 + 2 * nl]
+    g_rs_w, g_rs_b = dw[6 + 2 * nl: 6 + 3 * nl], dw[6 + 3 * nl: 6 + 4 * nl]
+    do = do.contiguous()
+    B, _, L = u0.shape
+    dev = u0.device
+
+    d_out = S.end.grad_x0(do, end_w)
+    if need_w:
+        S.end.grad_w(out, None, do, out0=g_end_w)
+        row_sum(do, out=g_end_b)
+    # Σ_{b,t} d_out: the res_skip bias gradient of the last layer, and the skip half of every other layer's
+    d_out_sum = row_sum(d_out, out=g_rs_b[nl - 1]) if need_w else None
+    d_a: Optional[Tensor] = None
+    d_a_sum: Optional[Tensor] = None      # Σ_{b,t} of the current d_a rows when the fused dgrad kernel left it behind
+    # res_skip bias gradients of layers 0..nl-2 = [Σ d_a ; Σ d_out] are consecutive segments: one [nl-1, 2n] view whose
+    # second half is the same for every layer (one broadcast) and whose first half is reduced straight into its row by
+    # the data-gradient launch of the layer above
+    d_rs_b_all = None
+    if need_w and nl > 1:
+        o0 = S.offsets[6 + 3 * nl]
+        d_rs_b_all = d_flat[o0: o0 + (nl - 1) * 2 * n].view(nl - 1, 2 * n)
+        d_rs_b_all[:, n:] = d_out_sum
+    fused_bwd = fused and os.environ.get("FST_WN_BWD", "fused") == "fused"          # diagnostics: =unfused
+    fused_dg = [fused and wn_dgrad_ok(n, h, 2 ** i) and os.environ.get("FST_WN_DGRAD", "fused") == "fused" for i in range(nl)]
+    # bias-gradient row sums: every fused launch leaves per-workgroup partials in its slab; ONE reduction per kind adds the
+    # slabs of all layers straight into the flat gradient's segments (instead of one reduction launch per layer and kind)
+    part_b = wn_bwd_partials(nl, B, L, dev) if (need_w and fused_bwd) else None
+    part_d = wn_dgrad_partials(nl, B, L, dev) if (need_w and all(fused_dg)) else None
+    for i in reversed(range(nl)):
+        last = i == nl - 1
+        # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
+        dacts = None if fused_bwd else torch.empty(B, n, L, device=dev, dtype=torch.float32)
+        if fused_bwd:
+            pass
+        elif last:
+            bf3 = bf3_ok(S.rs_T_last, L)
+            a_pk = pack_weights(S.rs_T_last, n, rs_w[i], (0, 1, n, 0), bf3=bf3)
+            conv_gemm(S.rs_T_last, a_pk, d_out, None, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0),
+                      bf3=bf3)
+        else:
+            bf3 = bf3_ok(S.rs_T, L)
+            a_pk = pack_weights(S.rs_T, n, rs_w[i], (0, 1, n, 0), rs_w[i], (n * n, 1, n, 0), bf3=bf3)
+            conv_gemm(S.rs_T, a_pk, d_a, d_out, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0),
+                      bf3=bf3)
+        if need_w:
+            # fused forward: acts = t·s is re-formed from the saved halves (rows [0,n) and [n,2n) of ts) while staging
+            x_rs = ts_list[i][:, :n] if fused else acts_list[i]
+            mul = n * L if fused else 0
+            if fused and os.environ.get("FST_WN_PROD", "1") == "0":                   # diagnostics: materialise acts
+                x_rs, mul = (ts_list[i][:, :n] * ts_list[i][:, n:]).contiguous(), 0
+            if last:
+                S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul, out0=g_rs_w[i])      # (its bias gradient is d_out_sum, in place)
+            else:
+                S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul, out0=g_rs_w[i])
+                if part_d is None and d_a_sum is None:   # not left behind by a fused data-gradient launch: one pass over d_a
+                    row_sum(d_a, out=d_rs_b_all[i, :n])
+        # ---- through the gate
+        dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
+        dg_sum = None
+        if fused_bwd:
+            dg_sum = wn_layer_bwd(None if last else d_a, d_out, ts_list[i], wn_pack_bwd(rs_w[i], n, last), dg, last, n,
+                                  want_row_sums=need_w, sums_out=g_in_b[i], part=None if part_b is None else part_b[i])
+        else:
+            check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]),
+                                   stream_ptr()), "fst_gate_bwd")
+        if need_w:
+            # in_layer weights and the layer's rows of the stacked cond_layer weights, unpacked in place
+            S.ins[i].grad_w(a_list[i], u0, dg, out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])
+            if dg_sum is None and part_b is None:     # fused: partials left by the backward kernel, reduced below
+                row_sum(dg, out=g_in_b[i])
+        # ---- into the layer input (residual path + dilated conv) and into the conditioning input
+        if fused_dg[i]:
+            img_d = wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h)
+            if need_w:
+                d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i, want_row_sums=True,
+                                              sums_out=d_rs_b_all[i - 1, :n] if i >= 1 else g_start_b,
+                                              part=None if part_d is None else part_d[i])
+            else:
+                d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i), None
+        else:
+            d_a, d_a_sum = S.ins[i].grad_x01(dg, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], d_a, d_u0), None
+    S.start.grad_x0(d_a, start_w, out=d_u0, flags=EPI_ACC1)
+    if need_w:
+        S.start.grad_w(u0, None, d_a, out0=g_start_w)
+        if part_b is not None:
+            # in_layer biases of all layers = consecutive segments: one [nl, 2n] reduction
+            o0 = S.offsets[6 + nl]
+            torch.sum(part_b[:, : 2 * n, :], dim=2, out=d_flat[o0: o0 + nl * 2 * n].view(nl, 2 * n))
+        if part_d is not None:
+            # Σ d_a entering layer i (left by the data-gradient launch of layer i) = residual half of res_skip bias i−1, and
+            # the start conv's bias gradient for i = 0
+            if nl > 1:
+                torch.sum(part_d[1:, :n, :], dim=2, out=d_rs_b_all[:, :n])
+            torch.sum(part_d[0, :n, :], dim=1, out=g_start_b)
+        elif d_a_sum is None:
+            row_sum(d_a, out=g_start_b)
+        # cond_layer bias = the in_layer biases, stacked (consecutive segments: one copy)
+        o0 = S.offsets[6 + nl]
+        g_cond_b.copy_(d_flat[o0: o0 + nl * 2 * n])
+    return d_flat
 
 
 class WNFn(torch.autograd.Function):
@@ -893,210 +1156,119 @@ class WNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, specs: WNSpecs, u0: Tensor, flat: Tensor):
-        lib = _lib.load()
-        S, nl = specs, specs.n_layers
-        flat = flat.contiguous()
-        weights = S.unflatten(flat)
-        start_w, start_b, cond_w, cond_b, end_w, end_b = weights[:6]
-        in_w, in_b = weights[6: 6 + nl], weights[6 + nl: 6 + 2 * nl]
-        rs_w, rs_b = weights[6 + 2 * nl: 6 + 3 * nl], weights[6 + 3 * nl: 6 + 4 * nl]
-        B, _, L = u0.shape
-        h, n = S.h, S.n
-        a = S.start.forward(u0, None, start_w, None, start_b)
-        a_list, ts_list, acts_list = [a], [], []
-        fused = wn_fused_ok(n, h, L, a, u0, kernel=S.kernel)
-        if fused:
-            # one launch per layer: dilated conv + cond rows → gate in registers → res_skip → residual / skip adds
-            out = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
-            cb = cond_b.view(nl, 2 * n)
-            for i in range(nl):
-                last = i == nl - 1
-                img = wn_pack_layer(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], in_b[i], cb[i], rs_w[i], rs_b[i], n, h, last)
-                ts = torch.empty(B, 2 * n, L, device=u0.device, dtype=torch.float32)
-                a_next = None if last else torch.empty_like(a)
-                # acts = t·s is not written: the res_skip weight gradient re-forms it from the saved halves while staging
-                wn_layer_fwd(a, u0, img, ts, None, a_next, out, i == 0, last, n, h, 2 ** i)
-                ts_list.append(ts)
-                if not last:
-                    a = a_next
-                    a_list.append(a)
-        else:
-            out = torch.zeros(B, n, L, device=u0.device, dtype=torch.float32)
-            bias_g = torch.stack(list(in_b)) + cond_b.view(nl, 2 * n)
-        for i in range(0 if fused else nl):
-            g = S.ins[i].forward(a, u0, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], bias_g[i])
-            acts = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
-            check(lib.fst_gate_fwd(ptr(g), ptr(acts), B, n, L, _gate_numel(acts, g), stream_ptr()), "fst_gate_fwd")
-            ts_list.append(g)
-            acts_list.append(acts)
-            if i < nl - 1:
-                a_next = torch.empty_like(a)
-                S.rs[i].forward(acts, None, rs_w[i], None, rs_b[i], y=a_next, res=a, y2=out, msplit=n, flags=EPI_ACC2)
-                a = a_next
-                a_list.append(a)
-            else:
-                S.rs[i].forward(acts, None, rs_w[i], None, rs_b[i], y=None, y2=out, msplit=0, flags=EPI_ACC2)
-        o = S.end.forward(out, None, end_w, None, end_b)
-        ctx.specs = S
-        ctx.fused = fused
-        if fused:
-            acts_list = ts_list                                           # placeholders (same count) for the saved-tensor layout
-        ctx.save_for_backward(u0, out, *a_list, *ts_list, *acts_list, flat)
+        o, fused, saved = _wn_forward(specs, u0, flat)
+        ctx.specs, ctx.fused = specs, fused
+        ctx.save_for_backward(*saved)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        lib = _lib.load()
-        S: WNSpecs = ctx.specs
-        nl, h, n = S.n_layers, S.h, S.n
-        sv = ctx.saved_tensors
-        u0, out = sv[0], sv[1]
-        a_list, ts_list, acts_list = sv[2: 2 + nl], sv[2 + nl: 2 + 2 * nl], sv[2 + 2 * nl: 2 + 3 * nl]
-        flat = sv[2 + 3 * nl]
-        weights = S.unflatten(flat)
-        start_w, cond_w, end_w = weights[0], weights[2], weights[4]
-        in_w, rs_w = weights[6: 6 + nl], weights[6 + 2 * nl: 6 + 3 * nl]
-        need_w = ctx.needs_input_grad[2] and _want_weight_grad()
-        # every gradient is written into its segment of one flat tensor; every segment is written in full (all WN convs have
-        # dense plans, the bias sums are stored, not accumulated), so the tensor needs no zero fill
-        d_flat = torch.empty_like(flat) if need_w else None
-        if need_w and os.environ.get("FST_DEBUG_POISON") == "1":          # tests: an unwritten element shows up as NaN
-            d_flat.fill_(float("nan"))
-        dw = S.unflatten(d_flat) if need_w else [None] * len(S.shapes)
-        g_start_w, g_start_b, g_cond_w, g_cond_b, g_end_w, g_end_b = dw[:6]
-        g_in_w, g_in_b = dw[6: 6 + nl], dw[6 + nl: 6 + 2 * nl]
-        g_rs_w, g_rs_b = dw[6 + 2 * nl: 6 + 3 * nl], dw[6 + 3 * nl: 6 + 4 * nl]
-        do = do.contiguous()
-        B, _, L = u0.shape
-        dev = u0.device
-
-        d_out = S.end.grad_x0(do, end_w)
-        if need_w:
-            S.end.grad_w(out, None, do, out0=g_end_w)
-            row_sum(do, out=g_end_b)
-        # Σ_{b,t} d_out: the res_skip bias gradient of the last layer, and the skip half of every other layer's
-        d_out_sum = row_sum(d_out, out=g_rs_b[nl - 1]) if need_w else None
-        d_u0 = torch.zeros(B, h, L, device=dev, dtype=torch.float32)
-        d_a: Optional[Tensor] = None
-        d_a_sum: Optional[Tensor] = None      # Σ_{b,t} of the current d_a rows when the fused dgrad kernel left it behind
-        # res_skip bias gradients of layers 0..nl-2 = [Σ d_a ; Σ d_out] are consecutive segments: one [nl-1, 2n] view whose
-        # second half is the same for every layer (one broadcast) and whose first half is reduced straight into its row by
-        # the data-gradient launch of the layer above
-        d_rs_b_all = None
-        if need_w and nl > 1:
-            o0 = S.offsets[6 + 3 * nl]
-            d_rs_b_all = d_flat[o0: o0 + (nl - 1) * 2 * n].view(nl - 1, 2 * n)
-            d_rs_b_all[:, n:] = d_out_sum
-        fused_bwd = ctx.fused and os.environ.get("FST_WN_BWD", "fused") == "fused"          # diagnostics: =unfused
-        fused_dg = [ctx.fused and wn_dgrad_ok(n, h, 2 ** i) and os.environ.get("FST_WN_DGRAD", "fused") == "fused" for i in range(nl)]
-        # bias-gradient row sums: every fused launch leaves per-workgroup partials in its slab; ONE reduction per kind adds the
-        # slabs of all layers straight into the flat gradient's segments (instead of one reduction launch per layer and kind)
-        part_b = wn_bwd_partials(nl, B, L, dev) if (need_w and fused_bwd) else None
-        part_d = wn_dgrad_partials(nl, B, L, dev) if (need_w and all(fused_dg)) else None
-        for i in reversed(range(nl)):
-            last = i == nl - 1
-            # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
-            dacts = None if fused_bwd else torch.empty(B, n, L, device=dev, dtype=torch.float32)
-            if fused_bwd:
-                pass
-            elif last:
-                bf3 = bf3_ok(S.rs_T_last, L)
-                a_pk = pack_weights(S.rs_T_last, n, rs_w[i], (0, 1, n, 0), bf3=bf3)
-                conv_gemm(S.rs_T_last, a_pk, d_out, None, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0),
-                          bf3=bf3)
-            else:
-                bf3 = bf3_ok(S.rs_T, L)
-                a_pk = pack_weights(S.rs_T, n, rs_w[i], (0, 1, n, 0), rs_w[i], (n * n, 1, n, 0), bf3=bf3)
-                conv_gemm(S.rs_T, a_pk, d_a, d_out, None, B, L, n, dacts, nb=S.start.nb_for(B, L, pick_mb(n), 0, 0),
-                          bf3=bf3)
-            if need_w:
-                # fused forward: acts = t·s is re-formed from the saved halves (rows [0,n) and [n,2n) of ts) while staging
-                x_rs = ts_list[i][:, :n] if ctx.fused else acts_list[i]
-                mul = n * L if ctx.fused else 0
-                if ctx.fused and os.environ.get("FST_WN_PROD", "1") == "0":                   # diagnostics: materialise acts
-                    x_rs, mul = (ts_list[i][:, :n] * ts_list[i][:, n:]).contiguous(), 0
-                if last:
-                    S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul, out0=g_rs_w[i])      # (its bias gradient is d_out_sum, in place)
-                else:
-                    S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul, out0=g_rs_w[i])
-                    if part_d is None and d_a_sum is None:   # not left behind by a fused data-gradient launch: one pass over d_a
-                        row_sum(d_a, out=d_rs_b_all[i, :n])
-            # ---- through the gate
-            dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
-            dg_sum = None
-            if fused_bwd:
-                dg_sum = wn_layer_bwd(None if last else d_a, d_out, ts_list[i], wn_pack_bwd(rs_w[i], n, last), dg, last, n,
-                                      want_row_sums=need_w, sums_out=g_in_b[i], part=None if part_b is None else part_b[i])
-            else:
-                check(lib.fst_gate_bwd(ptr(ts_list[i]), ptr(dacts), ptr(dg), B, n, L, _gate_numel(dacts, dg, ts_list[i]),
-                                       stream_ptr()), "fst_gate_bwd")
-            if need_w:
-                # in_layer weights and the layer's rows of the stacked cond_layer weights, unpacked in place
-                S.ins[i].grad_w(a_list[i], u0, dg, out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])
-                if dg_sum is None and part_b is None:     # fused: partials left by the backward kernel, reduced below
-                    row_sum(dg, out=g_in_b[i])
-            # ---- into the layer input (residual path + dilated conv) and into the conditioning input
-            if fused_dg[i]:
-                img_d = wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h)
-                if need_w:
-                    d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i, want_row_sums=True,
-                                                  sums_out=d_rs_b_all[i - 1, :n] if i >= 1 else g_start_b,
-                                                  part=None if part_d is None else part_d[i])
-                else:
-                    d_a, d_a_sum = wn_layer_dgrad(dg, img_d, d_a, d_u0, n, h, 2 ** i), None
-            else:
-                d_a, d_a_sum = S.ins[i].grad_x01(dg, in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], d_a, d_u0), None
-        S.start.grad_x0(d_a, start_w, out=d_u0, flags=EPI_ACC1)
-        if need_w:
-            S.start.grad_w(u0, None, d_a, out0=g_start_w)
-            if part_b is not None:
-                # in_layer biases of all layers = consecutive segments: one [nl, 2n] reduction
-                o0 = S.offsets[6 + nl]
-                torch.sum(part_b[:, : 2 * n, :], dim=2, out=d_flat[o0: o0 + nl * 2 * n].view(nl, 2 * n))
-            if part_d is not None:
-                # Σ d_a entering layer i (left by the data-gradient launch of layer i) = residual half of res_skip bias i−1, and
-                # the start conv's bias gradient for i = 0
-                if nl > 1:
-                    torch.sum(part_d[1:, :n, :], dim=2, out=d_rs_b_all[:, :n])
-                torch.sum(part_d[0, :n, :], dim=1, out=g_start_b)
-            elif d_a_sum is None:
-                row_sum(d_a, out=g_start_b)
-            # cond_layer bias = the in_layer biases, stacked (consecutive segments: one copy)
-            o0 = S.offsets[6 + nl]
-            g_cond_b.copy_(d_flat[o0: o0 + nl * 2 * n])
+        u0 = ctx.saved_tensors[0]
+        d_u0 = torch.zeros(u0.size(0), ctx.specs.h, u0.size(2), device=u0.device, dtype=torch.float32)
+        d_flat = _wn_backward(ctx.specs, ctx.fused, ctx.saved_tensors, do, d_u0, ctx.needs_input_grad[2] and _want_weight_grad())
         return None, (d_u0 if ctx.needs_input_grad[1] else None), d_flat
 
 
+def _coupling_forward(u: Tensor, o: Tensor):
+    """(x_next, Σ log_s, Σ x_next²) — the two sums as 0-d views of one reduced pair (fst_coupling_fwd leaves per-workgroup partials)."""
+    lib = _lib.load()
+    B, C, L = u.shape
+    xn = torch.empty_like(u)
+    part = torch.empty(lib.fst_coupling_sum_slots(B, C // 2, L), 2, device=u.device, dtype=torch.float32)
+    check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, _same_numel(u, o, xn), ptr(part), stream_ptr()),
+          "fst_coupling_fwd")
+    sums = part.sum(dim=0)
+    return xn, sums[0], sums[1]
+
+
+def _scalar_f32(g: Optional[Tensor]) -> Optional[Tensor]:
+    return None if g is None else g.contiguous().float()
+
+
+def _coupling_backward(u: Tensor, o: Tensor, dxn: Optional[Tensor], g_ls: Optional[Tensor], g_sq: Optional[Tensor]):
+    """(du [B, 2h, L], d_o) of the forward coupling given the cotangents of x_next and of the two sums (each may be None)."""
+    lib = _lib.load()
+    B, C, L = u.shape
+    if dxn is None and g_ls is None and g_sq is None:
+        return torch.zeros_like(u), torch.zeros_like(o)
+    du, d_o = torch.empty_like(u), torch.empty_like(o)
+    dxn = None if dxn is None else dxn.contiguous()
+    g_ls, g_sq = _scalar_f32(g_ls), _scalar_f32(g_sq)
+    check(lib.fst_coupling_bwd(ptr(u), ptr(o), ptr(dxn), None, ptr(g_ls), ptr(g_sq), ptr(du), ptr(d_o), B, C // 2, L,
+                               _same_numel(u, o, dxn, du, d_o), stream_ptr()), "fst_coupling_bwd")
+    return du, d_o
+
+
 class CouplingFn(torch.autograd.Function):
-    """x_next = cat(u0, exp(log_s)·u1 + b) with (b, log_s) = split(o) (:173-178).  Also returns [Σ log_s, Σ x_next²]
-    (a 2-element tensor) taken in the same pass: the full-tensor reductions of WaveGlowLoss (:230-241)."""
+    """x_next = cat(u0, exp(log_s)·u1 + b) with (b, log_s) = split(o) (:173-178).  Also returns Σ log_s and Σ x_next² (two 0-d
+    tensors) taken in the same pass: the full-tensor reductions of WaveGlowLoss (:230-241)."""
 
     @staticmethod
     def forward(ctx, u, o):
-        lib = _lib.load()
         u, o = u.contiguous(), o.contiguous()
-        B, C, L = u.shape
-        xn = torch.empty_like(u)
-        part = torch.empty(lib.fst_coupling_sum_slots(B, C // 2, L), 2, device=u.device, dtype=torch.float32)
-        check(lib.fst_coupling_fwd(ptr(u), ptr(o), ptr(xn), B, C // 2, L, _same_numel(u, o, xn), ptr(part), stream_ptr()),
-              "fst_coupling_fwd")
         ctx.save_for_backward(u, o)
         ctx.set_materialize_grads(False)      # an unused output's cotangent stays None (no [B, C, L] zero tensor to fill and read)
-        return xn, part.sum(dim=0)
+        return _coupling_forward(u, o)
 
     @staticmethod
-    def backward(ctx, dxn, dsums):
-        lib = _lib.load()
+    def backward(ctx, dxn, g_ls, g_sq):
         u, o = ctx.saved_tensors
-        B, C, L = u.shape
-        du, d_o = torch.empty_like(u), torch.empty_like(o)
-        dxn = None if dxn is None else dxn.contiguous()
-        gs = None if dsums is None else dsums.contiguous().float()
-        if dxn is None and gs is None:
-            return torch.zeros_like(u), torch.zeros_like(o)
-        check(lib.fst_coupling_bwd(ptr(u), ptr(o), ptr(dxn), None, ptr(gs), ptr(du), ptr(d_o), B, C // 2, L,
-                                   _same_numel(u, o, dxn, du, d_o), stream_ptr()), "fst_coupling_bwd")
-        return du, d_o
+        return _coupling_backward(u, o, dxn, g_ls, g_sq)
+
+
+class FlowFn(torch.autograd.Function):
+    """One flow step after its invertible 1x1 conv as ONE autograd node (Simplified_NF_WaveGlow.py:165-178 forward, :186-196
+    reverse):  o = WN(x[:, :h]);  x_next = coupling(x, o)  (``inverse``: the inverse coupling).
+
+    Returns (x_next, o, Σ log_s, Σ x_next²) (the sums are None in the inverse direction).  As separate nodes the WN's input
+    gradient [B, h, L] reaches ``x`` through a slice: autograd zero-fills a [B, 2h, L] tensor, copies the slice in and adds the
+    coupling's input gradient — three passes over the feature-sized tensor per flow and backward pass, plus the zero fill of the
+    WN's own d_u0.  Here the coupling backward writes the full-width gradient and the WN backward accumulates into its first h
+    channels in place (the data-gradient launches take a batch stride)."""
+
+    @staticmethod
+    def forward(ctx, specs: WNSpecs, x: Tensor, flat: Tensor, inverse: bool):
+        lib = _lib.load()
+        x = x.contiguous()
+        h = specs.h
+        assert x.size(1) == 2 * h
+        o, fused, saved = _wn_forward(specs, x[:, :h], flat)
+        B, C, L = x.shape
+        if inverse:
+            xn = torch.empty_like(x)
+            check(lib.fst_coupling_inv_fwd(ptr(x), ptr(o), ptr(xn), B, h, L, _same_numel(x, o, xn), stream_ptr()), "fst_coupling_inv_fwd")
+            s_ls = s_sq = None
+            keep = xn                                           # the inverse coupling's backward reads its OUTPUT
+        else:
+            xn, s_ls, s_sq = _coupling_forward(x, o)
+            keep = x
+        ctx.specs, ctx.fused, ctx.inverse = specs, fused, inverse
+        ctx.save_for_backward(keep, o, *saved)
+        ctx.set_materialize_grads(False)
+        return xn, o, s_ls, s_sq
+
+    @staticmethod
+    def backward(ctx, dxn, d_o_ext, g_ls, g_sq):
+        lib = _lib.load()
+        keep, o = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        sv = ctx.saved_tensors[2:]
+        S: WNSpecs = ctx.specs
+        B, C, L = keep.shape
+        if ctx.inverse:
+            if dxn is None:
+                dx, d_o = torch.zeros_like(keep), torch.zeros_like(o)
+            else:
+                dx, d_o = torch.empty_like(keep), torch.empty_like(o)
+                dxn = dxn.contiguous()
+                check(lib.fst_coupling_inv_bwd(ptr(keep), ptr(o), ptr(dxn), ptr(dx), ptr(d_o), B, S.h, L,
+                                               _same_numel(keep, o, dxn, dx, d_o), stream_ptr()), "fst_coupling_inv_bwd")
+        else:
+            dx, d_o = _coupling_backward(keep, o, dxn, g_ls, g_sq)
+        if d_o_ext is not None:                                   # someone differentiated the returned WN output itself
+            d_o = d_o + d_o_ext
+        need_w = ctx.needs_input_grad[2] and _want_weight_grad()
+        d_flat = _wn_backward(S, ctx.fused, sv, d_o, dx[:, : S.h], need_w)     # accumulates into the first h channels of dx
+        return None, (dx if ctx.needs_input_grad[1] else None), d_flat, None
 
 
 class CouplingInvFn(torch.autograd.Function):
@@ -1123,6 +1295,36 @@ class CouplingInvFn(torch.autograd.Function):
         check(lib.fst_coupling_inv_bwd(ptr(xn), ptr(o), ptr(dxn), ptr(dx), ptr(d_o), B, C // 2, L,
                                        _same_numel(xn, o, dxn, dx, d_o), stream_ptr()), "fst_coupling_inv_bwd")
         return dx, d_o
+
+
+class LogDetFn(torch.autograd.Function):
+    """log det W of a square fp32 matrix with torch.logdet's conventions (NaN for det < 0, -inf for det = 0), forward and the
+    gradient W^{-T} from ONE single-workgroup launch (fst_logdet_inv) — Simplified_NF_WaveGlow.py:40."""
+
+    @staticmethod
+    def forward(ctx, W: Tensor):
+        lib = _lib.load()
+        _lib.require_gpu_tensor(W, "W")
+        W = W.contiguous()
+        n = W.size(0)
+        assert W.dim() == 2 and W.size(1) == n and W.dtype == torch.float32
+        out = torch.empty(2, device=W.device, dtype=torch.float32)
+        inv_t = torch.empty_like(W)
+        check(lib.fst_logdet_inv(ptr(W), n, ptr(out), ptr(inv_t), stream_ptr()), "fst_logdet_inv")
+        ctx.save_for_backward(inv_t)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv_t,) = ctx.saved_tensors
+        return g * inv_t
+
+
+def logdet(W: Tensor) -> Tensor:
+    """``torch.logdet`` for the flow's 1x1 weights: the one-launch kernel up to 128 channels, stock torch beyond."""
+    if W.is_cuda and W.dim() == 2 and W.size(0) <= 128 and W.dtype == torch.float32:
+        return LogDetFn.apply(W)
+    return torch.logdet(W)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -37,13 +37,13 @@ class Invertible1x1Conv(nn.Module):
                 self.W_inverse = self.conv.weight.detach().squeeze().float().inverse()[..., None].contiguous()
             return ops.conv1d(self.spec, z.contiguous(), self.W_inverse, None)
         W = self.conv.weight
-        # inside WaveGlow.shared_fold() (one train step: W is the same for both forward passes) logdet(W) — an LU factorisation
-        # forward, a triangular solve backward, ~20 small launches — is taken once and its autograd node shared
+        # inside WaveGlow.shared_fold() (one train step: W is the same for both forward passes) logdet(W) is taken once and its
+        # autograd node shared
         cache = self._logdet_cache
         if cache is not None and cache[0] is not None:
             logdet = cache[0]
         else:
-            logdet = torch.logdet(W.squeeze())
+            logdet = ops.logdet(W.squeeze())
             if cache is not None:
                 cache[0] = logdet
         log_det_W = batch_size * n_of_groups * logdet
@@ -79,6 +79,7 @@ class WN(nn.Module):
             self.res_skip_layers.append(_wn_conv(n_channels, 2 * n_channels if i < n_layers - 1 else n_channels, 1))
         self.specs = ops.WNSpecs(n_in_channels, n_channels, n_layers, kernel_size)
         self._fold_cache = None
+        self._fold_plan = None
 
     def folded_weights(self) -> torch.Tensor:
         """Effective weights g·v/‖v‖ as ONE flat tensor in ``WNSpecs.shapes`` order.  Inside ``WaveGlow.shared_fold()`` (one
@@ -86,10 +87,32 @@ class WN(nn.Module):
         autograd graph is shared: the three applications' gradients are summed on the flat tensor (two adds per WN)."""
         if self._fold_cache is not None and self._fold_cache[0] is not None:
             return self._fold_cache[0]
-        flat = self.specs.flatten(self._fold())
+        if self.start.weight_v.is_cuda:
+            flat = ops.WNFoldFn.apply(self._plan(), *self._fold_inputs())        # one launch (18 weight-norm launches + a cat as torch ops)
+        else:
+            flat = self.specs.flatten(self._fold())
         if self._fold_cache is not None:
             self._fold_cache[0] = flat
         return flat
+
+    def _plan(self) -> "ops.WNFoldPlan":
+        if self._fold_plan is None:
+            nl = self.n_layers
+            normed = [True, False, True, False, False, False] + [True] * nl + [False] * nl + [True] * nl + [False] * nl
+            self._fold_plan = ops.WNFoldPlan(self.specs, normed)
+        return self._fold_plan
+
+    def _fold_inputs(self) -> List[torch.Tensor]:
+        """Parameter tensors in ``WNSpecs.shapes`` order, (v, g) for a weight-normed conv's weight."""
+        t = [self.start.weight_v, self.start.weight_g, self.start.bias, self.cond_layer.weight_v, self.cond_layer.weight_g,
+             self.cond_layer.bias, self.end.weight, self.end.bias]
+        for l in self.in_layers:
+            t += [l.weight_v, l.weight_g]
+        t += [l.bias for l in self.in_layers]
+        for l in self.res_skip_layers:
+            t += [l.weight_v, l.weight_g]
+        t += [l.bias for l in self.res_skip_layers]
+        return t
 
     def _fold(self) -> List[torch.Tensor]:
         w = [_folded(self.start), self.start.bias, _folded(self.cond_layer), self.cond_layer.bias,
@@ -144,22 +167,20 @@ class WaveGlow(nn.Module):
         for k in range(self.n_flows):
             audio, log_det_W = self.convinv[k](audio)
             log_det_W_list.append(log_det_W)
-            output = self.WN[k](audio[:, :n_half, :])
+            # WN on the first half of the channels + affine coupling as ONE autograd node (ops.FlowFn); Σ log_s of this flow (and
+            # Σ z² after the last one) are reduced inside the coupling kernel: WaveGlowLoss picks them up from the attributes below
+            # instead of re-reading the tensors (the returned tensors themselves are the reference's)
+            audio, output, s_ls, s_sq = ops.FlowFn.apply(self.WN[k].specs, audio, self.WN[k].folded_weights(), False)
             log_s = output[:, n_half:, :]
-            audio, sums = ops.CouplingFn.apply(audio, output)
-            # Σ log_s of this flow (and Σ z² after the last one) were reduced inside the coupling kernel; WaveGlowLoss picks
-            # them up from here instead of re-reading the tensors (the returned tensors themselves are the reference's)
-            log_s._fst_sum = sums[0]
-            audio._fst_sq_sum = sums[1]
+            log_s._fst_sum = s_ls
+            audio._fst_sq_sum = s_sq
             log_s_list.append(log_s)
         return audio, log_s_list, log_det_W_list
 
     def infer(self, audio: torch.Tensor, sigma: float = 1.0) -> torch.Tensor:
         n_half = self.n_group // 2
         for k in reversed(range(self.n_flows)):
-            audio = audio.contiguous()
-            output = self.WN[k](audio[:, :n_half, :])
-            audio = ops.CouplingInvFn.apply(audio, output)
+            audio = ops.FlowFn.apply(self.WN[k].specs, audio, self.WN[k].folded_weights(), True)[0]
             audio = self.convinv[k](audio, reverse=True)
         return audio
 

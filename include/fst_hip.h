@@ -180,14 +180,31 @@ int fst_gate_bwd(const float* ts, const float* dacts, float* dg, int B, int n, i
  * full-tensor reductions of WaveGlowLoss (Simplified_NF_WaveGlow.py:230-241) taken in the same pass; the caller adds the slots. */
 int64_t fst_coupling_sum_slots(int B, int h, int L);
 int fst_coupling_fwd(const float* u, const float* o, float* xn, int B, int h, int L, int64_t numel, float* sums, void* stream);
-/* backward of the above given dxn (may be NULL = 0) and (added) d_logs; gsums (optional DEVICE float[2]) = the cotangents of
- * the two sums: dxn_eff = dxn + 2·gsums[1]·xn, d log_s += gsums[0]; writes du (full 2h channels) and do */
-int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, const float* gsums,
+/* backward of the above given dxn (may be NULL = 0) and (added) d_logs; g_ls / g_sq (each optional, DEVICE scalars) = the
+ * cotangents of the two sums: dxn_eff = dxn + 2·g_sq·xn, d log_s += g_ls; writes du (full 2h channels) and do */
+int fst_coupling_bwd(const float* u, const float* o, const float* dxn, const float* dlogs, const float* g_ls, const float* g_sq,
                      float* du, float* d_o, int B, int h, int L, int64_t numel, void* stream);
 /* inverse coupling (:193-196): xn[:, h:] = (x[:, h:] − o[:, :h]) / exp(o[:, h:]) */
 int fst_coupling_inv_fwd(const float* x, const float* o, float* xn, int B, int h, int L, int64_t numel, void* stream);
 int fst_coupling_inv_bwd(const float* xn, const float* o, const float* dxn,
                          float* dx, float* d_o, int B, int h, int L, int64_t numel, void* stream);
+
+/* Weight-norm fold of every conv of one WN into the flat weight tensor the fused kernels read (and its backward), ONE launch per
+ * direction (Simplified_NF_WaveGlow.py:69-99: old-style weight_norm, w = g·v/‖v‖ per output channel, 18 convs per WN).
+ * table (DEVICE, n_rows x 6 int64): per row = one output channel of one conv, or one plain-copy segment (biases, the end conv):
+ *   { address of the row of v, address of the row's g scalar (0 = plain copy), element offset into flat, row length,
+ *     element offset of the row's v gradient in dpar, element offset of its g gradient in dpar }
+ * forward: flat[dst + j] = v[j]·g/‖v‖ (norms[r] = ‖v‖ kept for the backward);  backward: dv = (g/‖v‖)(dw − v (dw·v)/‖v‖²),
+ * dg = (dw·v)/‖v‖ written into the gradient buffer dpar (the caller hands out its segments as the parameters' gradients). */
+int fst_wn_fold_fwd(const int64_t* table_dev, int n_rows, float* flat, float* norms /* [n_rows] */, void* stream);
+int fst_wn_fold_bwd(const int64_t* table_dev, int n_rows, const float* d_flat, const float* norms, float* dpar, void* stream);
+
+/* log|det W| of the invertible 1x1 conv's [n][n] weight (Simplified_NF_WaveGlow.py:40, torch.logdet) and W^{-T}, the gradient
+ * d log|det W| / dW its backward needs, in ONE single-workgroup launch (in-place Gauss-Jordan with partial pivoting in double
+ * precision in LDS) instead of an LU factorisation, two triangular solves and ~30 tiny launches.  out[0] = log|det W| with
+ * torch.logdet's conventions (NaN for a negative determinant, -inf for a singular matrix), out[1] = sign(det);
+ * inv_t [n][n] = (W^{-1})^T (NaN-filled when singular).  n <= 128. */
+int fst_logdet_inv(const float* W, int n, float* out /* [2] */, float* inv_t /* [n][n] */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused WN layer (Simplified_NF_WaveGlow.py:101-123 with the gate of :44-54): ONE launch per layer
@@ -229,7 +246,8 @@ int fst_wn_layer_bwd(const float* d_a_next /* NULL iff last */, const float* d_o
  * 1x1 autograd derives for Simplified_NF_WaveGlow.py:107-112):
  *   d_a_new = d_a + Σ_τ W_in[:, :, τ]ᵀ · dg[t + (1 − τ)·dil]      (d_a NULL: no residual cotangent — the last layer)
  *   d_u0   += W_condᵀ · dg
- * in_w [2n][n][3], cond_w [2n][h] (this layer's rows); dg [B][2n][L]; d_a / d_a_new [B][n][L]; d_u0 [B][h][L] contiguous. */
+ * in_w [2n][n][3], cond_w [2n][h] (this layer's rows); dg [B][2n][L]; d_a / d_a_new [B][n][L]; d_u0 [B][h][L] with batch stride
+ * d_u0_bs (the first h channels of the coupling layer's full-width input gradient are accumulated into in place). */
 int64_t fst_wn_dgrad_image_bytes(int n);
 int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, int ntaps /* must be 3 */, void* image,
                       int64_t image_bytes, void* stream);
@@ -238,7 +256,7 @@ int fst_wn_pack_dgrad(const float* in_w, const float* cond_w, int n, int h, int 
 int fst_wn_dgrad_fits(int n, int h, int dil);
 int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, const float* d_a, float* d_a_new, float* d_u0,
                        float* row_sums /* optional [128][B·⌈L/512⌉]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
-                       int B, int L, int n, int h, int dil, int64_t numel_a, int64_t numel_u0, void* stream);
+                       int B, int L, int n, int h, int dil, int64_t numel_a, int64_t d_u0_bs, void* stream);
 
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */

@@ -8,8 +8,7 @@ against references that share nothing with the HIP kernels:
 * the WHOLE joint step, forward only, B=256 / L=512: nine losses, three logit tensors and the transferred feature against
   the CPU oracle from identical seeded state (train_and_test.py:547-603) — ``infer(forward(x)) = x`` cancels a WN-forward
   error, this does not;
-* the joint step with every accumulated gradient at B=32 / L=512, where the cancellation of Σ dy·x in front of a
-  train-mode BatchNorm is 8× milder than at B=4: the split-bf16 gates tighten accordingly.
+* the joint step with every accumulated gradient at B=32 / L=512 at the same gates as at B = 3-4.
 """
 import os
 
@@ -189,20 +188,14 @@ def test_forward_only_joint_step_full_batch_vs_oracle():
         close(aux[k], aux_o[k], 1e-4, f"B=256 forward {k}")
 
 
-# B=32: Σ dy·x in front of a train-mode BatchNorm cancels ~8× less than at B=4; measured on the MI355X (FST_GRAD_REPORT=1)
-GRAD_TOL_B32 = {"f32": {"default": 3e-4},
-                "bf16x3": {"default": 1e-4, "clf_t": 2e-3, "clf_s": 2e-3, "fe_t": 2e-3, "fe_s": 2e-3, "dimunif": 1e-3}}
-
-
-def test_joint_step_gradients_at_batch_32(arithmetic, monkeypatch):
-    """configs[1] geometry at B=32: every accumulated gradient of the whole step against the oracle, with the split-bf16
-    gates of the conv-in-front-of-BatchNorm modules at 2e-3 (5e-2 / 1e-2 at B = 3-4): the cancellation argument of
-    DESIGN.md §2 predicts the error fades with the batch, this is the test of that prediction."""
-    import test_gpu_full_step as S
+def test_joint_step_gradients_at_batch_32(arithmetic):
+    """configs[1] geometry at B=32: every accumulated gradient of the whole step against the oracle at the same gates as B = 3-4
+    (2e-4 split-bf16, 3e-5 exact f32).  Round 2 claimed the split-bf16 weight gradients in front of a BatchNorm were off by up to
+    2e-2 at small batches through cancellation and predicted that to fade with the batch; with every ReLU branch synchronised the
+    gradients agree to 7e-5 at B = 3, 4 and 32 alike (test_gpu_full_step.GRAD_TOL)."""
     L, Bq, seed = 512, 32, 3232
     js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=seed, dropout_p=0.0, zero_end=False)
     tr = _trainer_from(js, L, L, 4)
     gen = torch.Generator().manual_seed(seed + 1)
     batch = (_pair(gen, Bq, 1, L, 4), _pair(gen, Bq, 1, L, 4))
-    monkeypatch.setitem(S.GRAD_TOL, arithmetic, GRAD_TOL_B32[arithmetic])
     _check_step(*_step_both(js, tr, batch, (L // 8, L // 16)), tr, f"B=32 L={L} {arithmetic}", math=arithmetic)

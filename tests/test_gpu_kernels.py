@@ -263,14 +263,15 @@ def test_gate_and_coupling():
     r = torch.randn(B, 2 * h, L, generator=g, dtype=torch.float64)
     ((xn * r).sum() + o[:, h:].sum() * 0.5 + (xn * xn).sum() * 0.25).backward()
     ud, od = u.detach().float().to(DEV).requires_grad_(True), o.detach().float().to(DEV).requires_grad_(True)
-    xnd, sums = ops.CouplingFn.apply(ud, od)                             # sums = [Σ log_s, Σ xn²], reduced in the same pass
+    xnd, s_ls, s_sq = ops.CouplingFn.apply(ud, od)                       # Σ log_s, Σ xn²: reduced in the same pass
+    sums = (s_ls, s_sq)
     assert abs(float(sums[0]) - float(o[:, h:].sum())) <= 1e-5 * float(o[:, h:].abs().sum())
     assert abs(float(sums[1]) - float((xn * xn).sum())) <= 1e-5 * float((xn * xn).sum())
     ((xnd * r.float().to(DEV)).sum() + sums[0] * 0.5 + sums[1] * 0.25).backward()
     assert_close(xnd, xn, 1e-5, "coupling fwd"); assert_close(ud.grad, u.grad, 1e-5, "du"); assert_close(od.grad, o.grad, 1e-5, "do")
     # only the sums are used (no gradient reaches xn directly)
     ud2, od2 = ud.detach().clone().requires_grad_(True), od.detach().clone().requires_grad_(True)
-    _, sums2 = ops.CouplingFn.apply(ud2, od2)
+    _, *sums2 = ops.CouplingFn.apply(ud2, od2)
     (sums2[1] * 0.5 - sums2[0]).backward()
     u3, o3 = u.detach().clone().requires_grad_(True), o.detach().clone().requires_grad_(True)
     xn3 = torch.cat([u3[:, :h], torch.exp(o3[:, h:]) * u3[:, h:] + o3[:, :h]], 1)
@@ -577,3 +578,24 @@ def test_fused_wn_layer_data_gradient(n, h, B, L, dil, res):
     assert_close(d_u0, du_ref + d_u0_in, 2e-5, "d_u0")
     assert_close(sums, want_da.sum(dim=(0, 2)), 2e-5 * float(want_da.abs().sum(dim=(0, 2)).max()) / max(1e-9, float(want_da.sum(dim=(0, 2)).abs().max())),
                  "row sums of d_a (bias gradient)")
+
+
+@pytest.mark.parametrize("n", [1, 2, 6, 50, 128])
+def test_logdet_and_inverse_transpose_kernel(n):
+    """fst_logdet_inv against fp64 numpy: log|det W|, its gradient W^{-T}, and torch.logdet's conventions for det <= 0."""
+    import numpy as np
+    g = torch.Generator().manual_seed(n)
+    W = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))[0] + 0.3 * torch.randn(n, n, generator=g, dtype=torch.float64)
+    if np.linalg.slogdet(W.numpy())[0] < 0:
+        W[:, 0] = -W[:, 0]
+    Wd = W.float().to(DEV).requires_grad_(True)
+    ld = ops.logdet(Wd)
+    (ld * 1.7).backward()
+    sign, want = np.linalg.slogdet(W.float().double().numpy())
+    assert sign > 0 and abs(float(ld) - want) <= 1e-6 * max(1.0, abs(want))
+    assert_close(Wd.grad, 1.7 * torch.linalg.inv(W.float().double()).t(), 2e-6, "d logdet / dW = W^-T")
+    if n >= 2:
+        Wn = W.clone(); Wn[0] = -Wn[0]                                        # negative determinant -> NaN, like torch.logdet
+        assert torch.isnan(ops.logdet(Wn.float().to(DEV)))
+        Ws = W.clone(); Ws[1] = Ws[0]                                          # singular -> -inf
+        assert float(ops.logdet(Ws.float().to(DEV))) == float("-inf")
