@@ -42,43 +42,91 @@ def synthetic_batch(B, C_in, L, n_class, device, seed):
     return x.to(device), y.to(device)
 
 
-def cpu_baseline(L: int, pairs: int, steps: int, c_in: int = 1):
-    """The CPU oracle (oracle/restatement.py, a port of the reference's step) timed on this host's cores on a
-    bounded sample of the same workload.  Baseline only — never the product path.  The sample is `pairs` pairs per
-    step, not the metric's 256: a B=256 step of this path is ~100 s of CPU (the reference's own modules at
-    B=256, L=512 ran ≈2.5 pairs/s on 8 vCPUs; round 1's 16-pair sample on the GPU box's 16 threads gave 2.2-2.3), so
-    two of them plus a warm-up would be most of the bench's few-minutes budget; pairs/s is what is compared.  One more step is timed with autograd anomaly mode ON,
-    as the reference ships (train_and_test.py:24)."""
-    from oracle import restatement as R
-    # the GPU box gives one GPU a 16-CPU share; torch's default (all visible cores) oversubscribes it 8x
-    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
-    torch.manual_seed(1234)
-    js = R.build_joint_step(L, c_in, L, c_in, 4, 4, seed=1234)
-    g = torch.Generator().manual_seed(99)
-    mk = lambda: ((lambda x: (x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True))(torch.randn(pairs, c_in, L, generator=g)),
-                  torch.randint(4, (pairs,), generator=g))
-    (x_t, y_t), (x_s, y_s) = mk(), mk()
-    js.step(x_t, y_t, x_s, y_s, epoch=0)                                      # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        js.step(x_t, y_t, x_s, y_s, epoch=0)
-    dt = (time.perf_counter() - t0) / steps
-    t0 = time.perf_counter()
-    with torch.autograd.set_detect_anomaly(True, check_nan=True):
-        js.step(x_t, y_t, x_s, y_s, epoch=0)
-    dt_anomaly = time.perf_counter() - t0
-    model = "?"
+def host_cores():
+    """(threads to use, description): min(CPUs in this process's affinity mask, physical cores, cgroup CPU quota)."""
+    affinity = len(os.sched_getaffinity(0))
+    physical = None
     try:
+        ids, phys, core = set(), None, None
         with open("/proc/cpuinfo") as f:
-            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?")
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        ids.add((phys, core))
+                    phys = core = None
+        physical = len(ids) or None
     except OSError:
         pass
-    return {"value": pairs / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu_model": model, "host_logical_cpus": os.cpu_count(), "cpus_in_affinity": len(os.sched_getaffinity(0)),
-            "anomaly_mode_on": {"value": pairs / dt_anomaly, "unit": "samples/s", "steps": 1},
-            "sample": f"joint step S2 (L={L}, C_in={c_in}), {pairs} pairs/step (the metric's batch is 256: see the docstring), "
-                      f"{steps} timed steps after 1 warm-up ({steps * dt:.0f} s of CPU work), autograd anomaly mode off, "
-                      f"{dt:.2f} s/step; + 1 step with anomaly mode on ({dt_anomaly:.1f} s)"}
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(int(q) / int(period)))
+    except (OSError, ValueError):
+        pass
+    n = min(v for v in (affinity, physical, quota) if v)
+    return n, {"cpus_in_affinity": affinity, "physical_cores": physical, "cgroup_cpu_quota": quota, "host_logical_cpus": os.cpu_count()}
+
+
+def _time_oracle_steps(step, steps: int) -> float:
+    step()                                                                    # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    return (time.perf_counter() - t0) / steps
+
+
+def cpu_baseline(L: int, pairs: int, steps: int, c_in: int = 1, threads: int = 0, small_pairs: int = 16):
+    """The CPU oracle (oracle/restatement.py, a port of the reference's step) timed on this host's cores.  Baseline only —
+    never the product path.  Three measurements, all on `threads` threads = min(affinity, physical cores, cgroup quota)
+    unless --cpu-threads says otherwise:
+      * the headline: the joint step S2 at the METRIC's batch (`pairs`, default 256) — 1 warm-up + `steps` timed steps;
+      * S1, the classifier-only step (train_and_test.py:153-171), same batch;
+      * the small sample earlier rounds quoted (16 pairs/step, 3 steps), once more with autograd anomaly mode ON as the
+        reference ships (train_and_test.py:24) — kept for continuity (BatchNorm / CPC couple the batch and per-op overheads
+        weigh more at 16 pairs, so it is not the same workload)."""
+    from oracle import restatement as R
+    auto, host = host_cores()
+    torch.set_num_threads(threads or auto)
+    mk = lambda g, n: ((lambda x: (x - x.mean(-1, keepdim=True)) / x.std(-1, keepdim=True))(torch.randn(n, c_in, L, generator=g)),
+                       torch.randint(4, (n,), generator=g))
+
+    def joint(n_pairs, n_steps):
+        torch.manual_seed(1234)
+        js = R.build_joint_step(L, c_in, L, c_in, 4, 4, seed=1234)
+        g = torch.Generator().manual_seed(99)
+        (x_t, y_t), (x_s, y_s) = mk(g, n_pairs), mk(g, n_pairs)
+        return js, (x_t, y_t, x_s, y_s), _time_oracle_steps(lambda: js.step(x_t, y_t, x_s, y_s, epoch=0), n_steps)
+    _, _, dt = joint(pairs, steps)
+    out = {"value": pairs / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port", **host,
+           "sample": f"joint step S2 (L={L}, C_in={c_in}) at the metric's batch: {pairs} pairs/step, {steps} timed step(s) after 1 "
+                     f"warm-up, {dt:.1f} s/step, autograd anomaly mode off, {torch.get_num_threads()} threads"}
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["cpu_model"] = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?")
+    except OSError:
+        out["cpu_model"] = "?"
+    # S1 at the same batch
+    g = torch.Generator().manual_seed(7)
+    fe_spec, clf_spec = R.train_specs(L, c_in)
+    s1 = R.ClassifierStep(R.init_feature_extractor(fe_spec, g), R.init_classifier(clf_spec, 4, g), fe_spec, clf_spec)
+    x, y = mk(g, pairs)
+    dt1 = _time_oracle_steps(lambda: s1.step(x, y), 2)
+    out["s1_classifier_step"] = {"value": pairs / dt1, "unit": "samples/s", "s_per_step": dt1, "batch": pairs, "steps": 2}
+    if small_pairs and small_pairs != pairs:
+        js, batch, dts = joint(small_pairs, 3)
+        t0 = time.perf_counter()
+        with torch.autograd.set_detect_anomaly(True, check_nan=True):
+            js.step(*batch, epoch=0)
+        dta = time.perf_counter() - t0
+        out["small_sample"] = {"pairs_per_step": small_pairs, "value": small_pairs / dts, "unit": "samples/s", "steps": 3,
+                               "anomaly_mode_on": {"value": small_pairs / dta, "unit": "samples/s", "steps": 1}}
+    return out
 
 
 def self_launch(args) -> int:
@@ -207,8 +255,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
     ap.add_argument("--length", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs per step of the CPU baseline (default: --batch, the metric's batch)")
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: min(affinity, physical cores, cgroup quota))")
     ap.add_argument("--c-in", type=int, default=1, help="input channels of both domains (configs[3]: 9)")
     ap.add_argument("--sources", type=int, default=1,
                     help="independent source->target pipelines trained side by side on this GPU (configs[2]: 4); "
@@ -392,7 +441,7 @@ def main() -> None:
             torch.cuda.empty_cache()
             line["f32_mode"] = f32_mode_rate(args)
         if world == 1 and not args.plain and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.length, args.cpu_pairs, args.cpu_steps, args.c_in)
+            line["cpu_baseline"] = cpu_baseline(args.length, args.cpu_pairs or args.batch, args.cpu_steps, args.c_in, args.cpu_threads)
             line["gpu_over_cpu"] = value / args.sources / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -1,0 +1,409 @@
+// Weight gradients of a WaveGlow WN layer for gfx950 (the weight gradients autograd derives for
+// Simplified_NF_WaveGlow.py:107-116):
+//
+//   in_layer + cond_layer   dW_in[m][c][τ] = Σ_{b,t} dg[b,m,t]·a[b,c,t+(τ−1)·dil],   dW_cond[m][c] = Σ_{b,t} dg[b,m,t]·u0[b,c,t]
+//   res_skip                dW_rs[m][c]    = Σ_{b,t} [d_a ; d_out][b,m,t]·(t·s)[b,c,t]          (acts = t·s re-formed from the saved halves)
+//
+// A GEMM whose reduction index is TIME: D[m][k] = Σ_t dy[m][t]·x[k][t] with M = 2n output rows, K = 3n + h (or n) "k-rows"
+// and B·L = 131 072 reduction steps.  On v_mfma_f32_32x32x16_bf16 both operands are "row, 8 consecutive time samples" fragments,
+// i.e. 32 contiguous bytes of an fp32 activation row — no transposition anywhere.  Design, against the generic
+// conv_wgrad_kernel it replaces for these shapes (99 µs, MFMA-busy 0.24, 706 MB through L2 → LDS for 202 MB of operands):
+//   * one 8-wave workgroup per CU owns ALL 2n output rows × 192 k-rows (6 blocks; in_layer: two such groups, so dy passes the
+//     L2 → LDS path twice instead of four times) for a contiguous range of 32-sample time tiles;
+//   * operands reach LDS by LDS-DMA as raw fp32 rows of 32 samples (128 B), two slots, ONE barrier per tile; a row's eight
+//     16-byte pieces are XOR-swizzled by (row & 7) and every second octet of rows swaps row parity, so the fragment reads
+//     (two ds_read_b128 per fragment) are bank-conflict-free although rows are a multiple of 128 B apart;
+//   * each wave multiplies a 2 × 3 (res_skip: 2 × 2) tile of 32×32 blocks: five raw fragments are split into bf16 hi/lo in
+//     registers per k-step for 18 triple-MFMAs (hi·hi + hi·lo + lo·hi, fp32 accumulate);
+//   * a k-row count one past a multiple of 32 (3·120 + 25 = 385) does not cost a thirteenth block: the leftover row is
+//     accumulated on the VALU from the dy fragments the wave holds anyway;
+//   * every workgroup stores its partial D tile into its own slab (plain stores, two full 128-B segments per instruction);
+//     wn_wgrad_reduce_kernel adds the slabs in a fixed order and writes PyTorch layout: deterministic, no atomics.
+// Served: L % 32 == 0, n < 128 (M ≤ 256), h ≤ 32, tap shifts that are multiples of 4 samples (dil % 4 == 0), 16-byte aligned
+// tensors; everything else stays on conv_wgrad_kernel (fst_wn_wgrad_ok tells).
+#include "fst_common.h"
+
+typedef __bf16 ww_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ww_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ww_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ww_u32x4 __attribute__((ext_vector_type(4)));
+#define WW_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define WW_LDS_VOID(p) ((__attribute__((address_space(3))) void*)(p))
+
+#define WW_TT 32          // time samples per tile = one 128-byte LDS row
+#define WW_MROWS 256      // staged dy rows (8 blocks of 32)
+#define WW_MAX_NI 9       // LDS-DMA instructions (8 rows each) per wave and tile
+
+__device__ __attribute__((aligned(16))) float ww_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct WwSeg {
+  const float* ptr;     // rows of a [B][.][L] tensor: row c of sample b at ptr + b·bs + c·L
+  long long bs;         // batch stride (floats)
+  long long mul_off;    // product operand: the partner row lives mul_off floats further (t·s halves); 0 = none
+  int rows, shift;      // rows of this segment; time shift of the row's samples (x[k][t] = row[t + shift])
+  int out, out_off, out_sc, out_sm;   // reduce: k-row c of this segment, output row m → w[out][m·out_sm + c·out_sc + out_off]
+};
+
+struct WwParams {
+  WwSeg dy[2];          // output-row segments (M rows in all)
+  WwSeg x[4];           // k-row segments (K rows in all, the first K_main of them on the matrix cores)
+  int n_dy, n_x, M, K, K_main, n_extra;
+  int xr;               // staged k-rows per group = 32·2·KT
+  int mul;              // 1: every k-row is staged twice (row and partner) and multiplied when its fragment is read
+  int n_groups, ksplit, B, L, tiles_per_seq, n_tiles;
+  int R;                // staged rows per tile (multiple of 8)
+  int Kcols;            // slab row length = n_groups·xr
+  float* slab;          // [ksplit][256][Kcols]
+  float* slab_extra;    // [ksplit][256][2]
+  float* w[2];          // reduce outputs
+};
+
+__device__ __forceinline__ void ww_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const ww_f32x2 v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, ww_bf16x2));
+  const ww_f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ww_bf16x2));
+}
+
+__device__ __forceinline__ void ww_split8(const float4& v0, const float4& v1, ww_bf16x8& hi, ww_bf16x8& lo) {
+  ww_u32x4 h, l;
+  unsigned hh, ll;
+  ww_split_pair(v0.x, v0.y, hh, ll); h[0] = hh; l[0] = ll;
+  ww_split_pair(v0.z, v0.w, hh, ll); h[1] = hh; l[1] = ll;
+  ww_split_pair(v1.x, v1.y, hh, ll); h[2] = hh; l[2] = ll;
+  ww_split_pair(v1.z, v1.w, hh, ll); h[3] = hh; l[3] = ll;
+  hi = __builtin_bit_cast(ww_bf16x8, h);
+  lo = __builtin_bit_cast(ww_bf16x8, l);
+}
+
+template <int N>
+__device__ __forceinline__ void ww_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// logical staged row r, 16-byte piece q (0..7) → byte offset inside a slot: rows of odd octets swap parity, pieces are
+// XOR-swizzled by (r & 7): the sixteen lanes a ds_read_b128 services together then cover all 64 banks
+__device__ __forceinline__ int ww_lds_off(int r, int q) { return ((r ^ ((r >> 3) & 1)) << 7) + (((q ^ r) & 7) << 4); }
+
+template <int MT, int KT>
+__global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
+  extern __shared__ __attribute__((aligned(16))) char ww_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_s >> 1, wk = wave_s & 1;          // 4 (output-row pairs) × 2 (k-row halves of the group)
+  const int g = blockIdx.y, L = p.L;
+  const int slot_bytes = p.R * 128;
+  const char* const zero16 = reinterpret_cast<const char*>(ww_zero16);
+
+  // ---- per (LDS-DMA instruction of this wave, lane): which 16 bytes of which tensor row it fetches.  Instruction i fills the
+  // LDS rows 8i..8i+7 (1 KiB, lane-linear); lane → LDS row 8i + (lane >> 3), piece slot lane & 7 → logical row / piece by the
+  // inverse of ww_lds_off.  Staged rows: [0, 256) dy rows, [256, 256 + xr) this group's k-rows, [.., + xr) their partners
+  // (product operand), then one octet for the leftover rows (group 0 only).
+  const int NI = p.R >> 3;
+  const int my_ni = (NI - wave_s + 7) >> 3;               // instructions i = wave, wave + 8, ...  (wave-uniform count)
+  const float* src0[WW_MAX_NI];                           // address of the piece in batch element 0 at t0 = 0 (null: zero fill)
+  int src_bs[WW_MAX_NI], src_t[WW_MAX_NI];                // batch stride (floats); first sample of the piece relative to t0
+#pragma unroll
+  for (int k = 0; k < WW_MAX_NI; ++k) {
+    src0[k] = nullptr; src_bs[k] = 0; src_t[k] = 0;
+    const int i = wave_s + 8 * k;
+    if (k >= my_ni) continue;
+    const int r = 8 * i + ((lane >> 3) ^ (i & 1));
+    const int q = (lane ^ r) & 7;
+    int which = -1, c = 0;                                 // 0, 1: dy segments; 2..5: x segments
+    bool partner = false;
+    if (r < WW_MROWS) {
+      if (r < p.M) {
+        if (p.n_dy > 1 && r >= p.dy[0].rows) { which = 1; c = r - p.dy[0].rows; } else { which = 0; c = r; }
+      }
+    } else {
+      const int rr = r - WW_MROWS;
+      int kk = -1;
+      if (rr < p.xr) kk = g * p.xr + rr;
+      else if (p.mul && rr < 2 * p.xr) { kk = g * p.xr + rr - p.xr; partner = true; }
+      else {
+        const int e = rr - p.xr * (1 + p.mul);            // leftover rows: the k-rows K_main .. K-1, staged by group 0
+        if (g == 0 && e < p.n_extra) kk = p.K_main + e;
+      }
+      if (kk >= 0 && kk < p.K && (kk < p.K_main || rr >= p.xr * (1 + p.mul))) {
+        int s = 0, c0 = kk;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (s + 1 < p.n_x && c0 >= p.x[s].rows) { c0 -= p.x[s].rows; ++s; }
+        which = 2 + s; c = c0;
+      }
+    }
+    // the segment's fields by a chain of compares (kernel arguments are read with scalar loads; no pointer into the argument block)
+    const float* sp = nullptr;
+    long long sbs = 0, smo = 0;
+    int ssh = 0;
+#define WW_PICK(W, SEG) if (which == (W)) { sp = SEG.ptr; sbs = SEG.bs; smo = SEG.mul_off; ssh = SEG.shift; }
+    WW_PICK(0, p.dy[0]) WW_PICK(1, p.dy[1]) WW_PICK(2, p.x[0]) WW_PICK(3, p.x[1]) WW_PICK(4, p.x[2]) WW_PICK(5, p.x[3])
+#undef WW_PICK
+    if (which >= 0) {
+      src0[k] = sp + ((long long)c * L + ssh + 4 * q) + (partner ? smo : 0);
+      src_bs[k] = (int)sbs;
+      src_t[k] = ssh + 4 * q;
+    }
+  }
+
+  auto issue = [&](int tile, int slot) {
+    const int b = tile / p.tiles_per_seq;
+    const int t0 = (tile - b * p.tiles_per_seq) * WW_TT;
+    char* const sl = ww_lds + slot * slot_bytes;
+#pragma unroll
+    for (int k = 0; k < WW_MAX_NI; ++k) {
+      if (k >= my_ni) break;                              // wave-uniform
+      const int i = wave_s + 8 * k;
+      const int t = t0 + src_t[k];
+      const bool ok = src0[k] != nullptr && t >= 0 && t < L;
+      const char* src = ok ? reinterpret_cast<const char*>(src0[k] + ((long long)b * src_bs[k] + t0)) : zero16;
+      __builtin_amdgcn_global_load_lds(WW_GLOBAL_PTR(src), WW_LDS_VOID(sl + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MT][KT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float ev[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) ev[i][0] = ev[i][1] = 0.f;
+
+  const int tile_begin = (int)(((long long)blockIdx.x * p.n_tiles) / p.ksplit);
+  const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.n_tiles) / p.ksplit);
+  const int m_blocks = (p.M + 31) >> 5;
+  const int k_blocks_here = min(2 * KT, ((p.K_main + 31) >> 5) - g * 2 * KT);   // live k-row blocks of this group
+  const bool do_extra = g == 0 && wk == 0 && p.n_extra > 0;
+
+  // fragment addressing: row block·32 + l31, pieces (4·ks + 2·half) and the next one
+  const int row_l = (l31 ^ ((l31 >> 3) & 1)) << 7;        // ww_lds_off's row term for a row ≡ l31 (mod 32)
+  const int sw = l31 & 7;
+  int pc[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    pc[ks][0] = (((4 * ks + 2 * half) ^ sw) & 7) << 4;
+    pc[ks][1] = (((4 * ks + 2 * half + 1) ^ sw) & 7) << 4;
+  }
+  const int x_base = (WW_MROWS + wk * KT * 32) << 7, xp_base = x_base + (p.xr << 7);
+  const int e_base = (WW_MROWS + p.xr * (1 + p.mul)) << 7;
+
+  if (tile_begin < tile_end) issue(tile_begin, 0);
+  int slot = 0;
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    ww_wait_vmcnt<0>();                                    // this wave's pieces of the tile have landed (nothing else is in flight)
+    __builtin_amdgcn_s_barrier();                          // ... everyone's have, and everyone is done reading the other slot
+    if (tile + 1 < tile_end) issue(tile + 1, slot ^ 1);
+    const char* const sl = ww_lds + slot * slot_bytes;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      ww_bf16x8 ah[MT], al[MT];
+      float4 araw[MT][2];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const char* ap = sl + (((wm * MT + i) * 32) << 7) + row_l;
+        araw[i][0] = *reinterpret_cast<const float4*>(ap + pc[ks][0]);
+        araw[i][1] = *reinterpret_cast<const float4*>(ap + pc[ks][1]);
+        ww_split8(araw[i][0], araw[i][1], ah[i], al[i]);
+      }
+      if (do_extra) {
+        // leftover k-rows on the VALU: every lane of a half reads the same 8 samples of the row (a broadcast), lane = output row
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (e >= p.n_extra) break;
+          const char* ep = sl + e_base + (e << 7);
+          const float4 x0 = *reinterpret_cast<const float4*>(ep + ((((4 * ks + 2 * half) ^ e) & 7) << 4));
+          const float4 x1 = *reinterpret_cast<const float4*>(ep + ((((4 * ks + 2 * half + 1) ^ e) & 7) << 4));
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            ev[i][e] += (araw[i][0].x * x0.x + araw[i][0].y * x0.y) + (araw[i][0].z * x0.z + araw[i][0].w * x0.w) +
+                        (araw[i][1].x * x1.x + araw[i][1].y * x1.y) + (araw[i][1].z * x1.z + araw[i][1].w * x1.w);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        if (wk * KT + j >= k_blocks_here) break;           // wave-uniform: blocks beyond K hold zeros
+        const char* bp = sl + x_base + ((j * 32) << 7) + row_l;
+        float4 b0 = *reinterpret_cast<const float4*>(bp + pc[ks][0]);
+        float4 b1 = *reinterpret_cast<const float4*>(bp + pc[ks][1]);
+        if (p.mul) {                                       // kernel argument: uniform
+          const char* qp = sl + xp_base + ((j * 32) << 7) + row_l;
+          const float4 c0 = *reinterpret_cast<const float4*>(qp + pc[ks][0]);
+          const float4 c1 = *reinterpret_cast<const float4*>(qp + pc[ks][1]);
+          b0.x *= c0.x; b0.y *= c0.y; b0.z *= c0.z; b0.w *= c0.w;
+          b1.x *= c1.x; b1.y *= c1.y; b1.z *= c1.z; b1.w *= c1.w;
+        }
+        ww_bf16x8 bh, bl;
+        ww_split8(b0, b1, bh, bl);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (wm * MT + i >= m_blocks) break;              // wave-uniform
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    slot ^= 1;
+  }
+
+  // ---- partial D tile → this workgroup's slab: register r of a tile = output row (r&3) + 8(r>>2) + 4·half, lane & 31 = k-row:
+  // one wave-instruction stores two rows × 32 consecutive floats
+  float* const slab = p.slab + (long long)blockIdx.x * WW_MROWS * p.Kcols;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if (wm * MT + i >= m_blocks) break;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      if (wk * KT + j >= k_blocks_here) break;
+      float* dst = slab + (long long)((wm * MT + i) * 32 + 4 * half) * p.Kcols + g * p.xr + (wk * KT + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(long long)((r & 3) + 8 * (r >> 2)) * p.Kcols] = acc[i][j][r];
+    }
+  }
+  if (do_extra) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (wm * MT + i >= m_blocks) break;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float s = ev[i][e] + __shfl_xor(ev[i][e], 32, 64);
+        if (half == 0 && e < p.n_extra) p.slab_extra[((long long)blockIdx.x * WW_MROWS + (wm * MT + i) * 32 + l31) * 2 + e] = s;
+      }
+    }
+  }
+}
+
+// out[m][k-row] = Σ_slabs, written in PyTorch layout: k-row kk of x segment s, channel c → w[seg.out][m·out_sm + c·out_sc + out_off]
+__global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(WwParams p) {
+  const int Kt = p.K_main < p.K ? p.K_main + p.n_extra : p.K;      // k-rows with a result
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)p.M * Kt) return;
+  const int m = (int)(idx / Kt), kk = (int)(idx - (long long)m * Kt);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (kk < p.K_main) {
+    const float* q = p.slab + (long long)m * p.Kcols + kk;
+    const long long st = (long long)WW_MROWS * p.Kcols;
+    int s = 0;
+    for (; s + 4 <= p.ksplit; s += 4) { s0 += q[s * st]; s1 += q[(s + 1) * st]; s2 += q[(s + 2) * st]; s3 += q[(s + 3) * st]; }
+    for (; s < p.ksplit; ++s) s0 += q[s * st];
+  } else {
+    const float* q = p.slab_extra + (long long)m * 2 + (kk - p.K_main);
+    for (int s = 0; s < p.ksplit; ++s) s0 += q[(long long)s * WW_MROWS * 2];
+  }
+  const float sum = (s0 + s1) + (s2 + s3);
+  int si = 0, c = kk;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    if (si + 1 < p.n_x && c >= p.x[si].rows) { c -= p.x[si].rows; ++si; }
+  const WwSeg& seg = p.x[si];
+  p.w[seg.out][(long long)m * seg.out_sm + (long long)c * seg.out_sc + seg.out_off] = sum;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static inline bool ww_al16(const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+// geometry shared by the size query and the launchers; kind 0 = in_layer + cond_layer, 1 = res_skip
+static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams* p) {
+  const int KT = kind == 0 ? 3 : 2;
+  p->M = kind == 0 ? 2 * n : (last ? n : 2 * n);
+  p->K = kind == 0 ? 3 * n + h : n;
+  const int rem = p->K & 31;
+  p->n_extra = (kind == 0 && rem >= 1 && rem <= 2) ? rem : 0;      // one or two k-rows past a multiple of 32: VALU rows
+  p->K_main = p->n_extra ? p->K - rem : p->K;
+  p->xr = 32 * 2 * KT;
+  const int kb = (p->K_main + 31) / 32;
+  p->n_groups = (kb + 2 * KT - 1) / (2 * KT);
+  p->mul = kind == 1;
+  p->R = WW_MROWS + p->xr * (1 + p->mul) + (p->n_extra ? 8 : 0);
+  p->Kcols = p->n_groups * p->xr;
+  p->B = B; p->L = L;
+  p->tiles_per_seq = L / WW_TT;
+  p->n_tiles = B * p->tiles_per_seq;
+  const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
+  int ks = cus / p->n_groups;
+  if (ks < 1) ks = 1;
+  if (ks > p->n_tiles) ks = p->n_tiles;
+  p->ksplit = ks;
+  return KT;
+}
+
+extern "C" int fst_wn_wgrad_ok(int kind, int B, int L, int n, int h, int dil) {
+  if (!(B > 0 && L > 0 && L % WW_TT == 0 && n > 0 && n < 128)) return 0;
+  if (kind == 0) return h > 0 && h <= 32 && dil > 0 && dil % 4 == 0 && (3 * n + h + 31) / 32 <= 18;
+  return kind == 1;
+}
+
+extern "C" int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, int h, int last) {
+  if (!fst_wn_wgrad_ok(kind, B, L, n, h, 4)) return -1;
+  WwParams p;
+  ww_geometry(kind, B, L, n, h, last, &p);
+  return (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2);
+}
+
+static int ww_launch(WwParams& p, int KT, void* stream) {
+  const size_t lds = (size_t)2 * p.R * 128;
+  FST_REQUIRE(lds <= 160 * 1024 && (p.R >> 3) <= 8 * WW_MAX_NI, "fst_wn_wgrad: %d staged rows per tile do not fit (LDS %zu B)", p.R, lds);
+  void (*fn)(WwParams) = KT == 3 ? wn_wgrad_kernel<2, 3> : wn_wgrad_kernel<2, 2>;
+  if (int rc = fst_allow_full_lds((const void*)fn, "fst_wn_wgrad")) return rc;
+  hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  const int Kt = p.K_main < p.K ? p.K_main + p.n_extra : p.K;
+  const long long total = (long long)p.M * Kt;
+  hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0, int64_t u0_bs, float* dw_in, float* dw_cond,
+                               float* workspace, int64_t workspace_floats, int B, int L, int n, int h, int dil, int64_t numel_a,
+                               void* stream) {
+  FST_REQUIRE(dg && a && u0 && dw_in && dw_cond && workspace, "fst_wn_wgrad_in: null operand");
+  FST_REQUIRE(fst_wn_wgrad_ok(0, B, L, n, h, dil), "fst_wn_wgrad_in: unsupported shape B=%d L=%d n=%d h=%d dil=%d (needs L %% 32 == 0, "
+              "n < 128, h <= 32, dil %% 4 == 0)", B, L, n, h, dil);
+  FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_in: B*n*L does not match the element count %lld of a", (long long)numel_a);
+  FST_REQUIRE(B == 1 || u0_bs >= (int64_t)h * L, "fst_wn_wgrad_in: u0 batch stride %lld < h*L", (long long)u0_bs);
+  FST_REQUIRE(u0_bs % 4 == 0 && ww_al16(dg) && ww_al16(a) && ww_al16(u0) && ww_al16(workspace), "fst_wn_wgrad_in: operands must be 16-byte aligned");
+  WwParams p = {};
+  const int KT = ww_geometry(0, B, L, n, h, 0, &p);
+  FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2), "fst_wn_wgrad_in: workspace of %lld floats is too small",
+              (long long)workspace_floats);
+  p.n_dy = 1;
+  p.dy[0] = {dg, (long long)2 * n * L, 0, 2 * n, 0, 0, 0, 0, 0};
+  p.n_x = 4;
+  for (int tap = 0; tap < 3; ++tap) p.x[tap] = {a, (long long)n * L, 0, n, (tap - 1) * dil, 0, tap, 3, 3 * n};
+  p.x[3] = {u0, (long long)u0_bs, 0, h, 0, 1, 0, 1, h};
+  p.slab = workspace;
+  p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
+  p.w[0] = dw_in; p.w[1] = dw_cond;
+  return ww_launch(p, KT, stream);
+}
+
+extern "C" int fst_wn_wgrad_rs(const float* d_a, const float* d_out, const float* ts, float* dw_rs, float* workspace,
+                               int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a, void* stream) {
+  FST_REQUIRE(d_out && ts && dw_rs && workspace && (last || d_a), "fst_wn_wgrad_rs: null operand");
+  FST_REQUIRE(fst_wn_wgrad_ok(1, B, L, n, 0, 4), "fst_wn_wgrad_rs: unsupported shape B=%d L=%d n=%d (needs L %% 32 == 0, n < 128)", B, L, n);
+  FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_rs: B*n*L does not match the element count %lld", (long long)numel_a);
+  FST_REQUIRE(ww_al16(d_a) && ww_al16(d_out) && ww_al16(ts) && ww_al16(workspace), "fst_wn_wgrad_rs: operands must be 16-byte aligned");
+  WwParams p = {};
+  const int KT = ww_geometry(1, B, L, n, 0, last, &p);
+  FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2), "fst_wn_wgrad_rs: workspace of %lld floats is too small",
+              (long long)workspace_floats);
+  if (last) {
+    p.n_dy = 1;
+    p.dy[0] = {d_out, (long long)n * L, 0, n, 0, 0, 0, 0, 0};
+  } else {
+    p.n_dy = 2;
+    p.dy[0] = {d_a, (long long)n * L, 0, n, 0, 0, 0, 0, 0};
+    p.dy[1] = {d_out, (long long)n * L, 0, n, 0, 0, 0, 0, 0};
+  }
+  p.n_x = 1;
+  p.x[0] = {ts, (long long)2 * n * L, (long long)n * L, n, 0, 0, 0, 1, n};   // t rows; the s rows n·L floats further
+  p.slab = workspace;
+  p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
+  p.w[0] = dw_rs; p.w[1] = nullptr;
+  return ww_launch(p, KT, stream);
+}

@@ -714,6 +714,54 @@ class WNSpecs:
         return [flat[self.offsets[i]: self.offsets[i + 1]].view(sh) for i, sh in enumerate(self.shapes)]
 
 
+def wn_wgrad_ok(kind: int, B: int, L: int, n: int, h: int, dil: int) -> bool:
+    """Whether the time-as-k weight-gradient kernels of csrc/wn_wgrad.hip serve this layer (kind 0 = in_layer + cond_layer,
+    1 = res_skip): split-bf16 arithmetic, L % 32 == 0, n < 128, h <= 32, tap shifts that are multiples of 4 samples.  Everything
+    else stays on the generic fst_conv_wgrad."""
+    if MATH != "bf16x3" or os.environ.get("FST_WN_WGRAD", "1") == "0":
+        return False
+    return bool(_lib.load().fst_wn_wgrad_ok(kind, B, L, n, h, dil))
+
+
+def wn_wgrad_in(dg: Tensor, a: Tensor, u0: Tensor, dw_in: Tensor, dw_cond: Tensor, n: int, h: int, dil: int) -> None:
+    """dw_in [2n, n, 3] = Σ dg ⊗ a(t + (τ−1)·dil),  dw_cond [2n, h, 1] = Σ dg ⊗ u0 — written in place (fst_wn_wgrad_in)."""
+    lib = _lib.load()
+    B, _, L = dg.shape
+    u0_bs, _ = _ncl(u0, "u0")
+    numel = _same_numel(a)
+    if dg.numel() != 2 * numel or not dg.is_contiguous() or tuple(a.shape) != (B, n, L) or tuple(u0.shape) != (B, h, L):
+        raise ValueError("wn_wgrad_in: dg must be contiguous [B, 2n, L], a [B, n, L], u0 [B, h, L]")
+    for t, sh in ((dw_in, (2 * n, n, 3)), (dw_cond, (2 * n, h, 1))):
+        if tuple(t.shape) != sh or not t.is_contiguous() or t.dtype != torch.float32:
+            raise ValueError(f"wn_wgrad_in: gradient target of shape {tuple(t.shape)}, expected contiguous {sh}")
+    ws_n = lib.fst_wn_wgrad_workspace_floats(0, B, L, n, h, 0)
+    ws = torch.empty(ws_n, device=dg.device, dtype=torch.float32)
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_wn_wgrad_in(ptr(dg), ptr(a), ptr(u0), u0_bs, ptr(dw_in), ptr(dw_cond), ptr(ws), ws_n, B, L, n, h, dil, numel,
+                              stream_ptr()), "fst_wn_wgrad_in")
+    if t0 is not None:
+        KERNEL_TIMER.end("wn_wgrad_kernel<2, 3>", t0, 2.0 * B * L * 2 * n * (3 * n + h), 4.0 * B * L * (2 * n + n + h))
+
+
+def wn_wgrad_rs(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, dw_rs: Tensor, last: bool, n: int) -> None:
+    """dw_rs [2n | n, n, 1] = Σ [d_a ; d_out] ⊗ (t·s), acts = t·s re-formed from the saved gate halves ts [B, 2n, L] (fst_wn_wgrad_rs)."""
+    lib = _lib.load()
+    B, _, L = d_out.shape
+    numel = _same_numel(d_out, d_a)
+    M = n if last else 2 * n
+    if ts.numel() != 2 * numel or not ts.is_contiguous() or (d_a is None) != bool(last):
+        raise ValueError("wn_wgrad_rs: ts must be contiguous [B, 2n, L]; d_a is None exactly on the last layer")
+    if tuple(dw_rs.shape) != (M, n, 1) or not dw_rs.is_contiguous() or dw_rs.dtype != torch.float32:
+        raise ValueError(f"wn_wgrad_rs: gradient target of shape {tuple(dw_rs.shape)}, expected contiguous {(M, n, 1)}")
+    ws_n = lib.fst_wn_wgrad_workspace_floats(1, B, L, n, 0, int(last))
+    ws = torch.empty(ws_n, device=d_out.device, dtype=torch.float32)
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_wn_wgrad_rs(ptr(d_a), ptr(d_out), ptr(ts), ptr(dw_rs), ptr(ws), ws_n, int(last), B, L, n, numel, stream_ptr()),
+          "fst_wn_wgrad_rs")
+    if t0 is not None:
+        KERNEL_TIMER.end("wn_wgrad_kernel<2, 2>", t0, 2.0 * B * L * M * n, 4.0 * B * L * (M + 2 * n))
+
+
 class WNFoldPlan:
     """Row table of ``WNFoldFn`` for one WN: which parameter tensors (weight-normed (v, g) pairs and plain tensors, in
     ``WNSpecs.shapes`` order) fill which segment of the flat weight tensor.  The device table holds the parameters' ADDRESSES: it is
@@ -1091,7 +1139,9 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
             mul = n * L if fused else 0
             if fused and os.environ.get("FST_WN_PROD", "1") == "0":                   # diagnostics: materialise acts
                 x_rs, mul = (ts_list[i][:, :n] * ts_list[i][:, n:]).contiguous(), 0
-            if last:
+            if fused and mul and wn_wgrad_ok(1, B, L, n, h, 2 ** i):
+                wn_wgrad_rs(None if last else d_a, d_out, ts_list[i], g_rs_w[i], last, n)
+            elif last:
                 S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul, out0=g_rs_w[i])      # (its bias gradient is d_out_sum, in place)
             else:
                 S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul, out0=g_rs_w[i])
@@ -1108,7 +1158,10 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
                                    stream_ptr()), "fst_gate_bwd")
         if need_w:
             # in_layer weights and the layer's rows of the stacked cond_layer weights, unpacked in place
-            S.ins[i].grad_w(a_list[i], u0, dg, out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])
+            if fused and wn_wgrad_ok(0, B, L, n, h, 2 ** i):
+                wn_wgrad_in(dg, a_list[i], u0, g_in_w[i], g_cond_w[2 * n * i: 2 * n * (i + 1)], n, h, 2 ** i)
+            else:
+                S.ins[i].grad_w(a_list[i], u0, dg, out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])
             if dg_sum is None and part_b is None:     # fused: partials left by the backward kernel, reduced below
                 row_sum(dg, out=g_in_b[i])
         # ---- into the layer input (residual path + dilated conv) and into the conditioning input

@@ -258,6 +258,20 @@ int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, 
                        float* row_sums /* optional [128][B·⌈L/512⌉]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
                        int B, int L, int n, int h, int dil, int64_t numel_a, int64_t d_u0_bs, void* stream);
 
+/* Weight gradients of the same layer (the gradients autograd derives for Simplified_NF_WaveGlow.py:107-116), time as the MFMA
+ * reduction index, split-bf16 products, per-workgroup partial slabs added in a fixed order (deterministic, no atomics):
+ *   fst_wn_wgrad_in   dw_in[m][c][τ] = Σ_{b,t} dg[b,m,t]·a[b,c,t+(τ−1)·dil]   ([2n][n][3]),   dw_cond[m][c] = Σ dg[b,m,t]·u0[b,c,t]  ([2n][h])
+ *   fst_wn_wgrad_rs   dw_rs[m][c] = Σ_{b,t} [d_a ; d_out][b,m,t]·(t·s)[b,c,t]  ([2n][n]; last layer: d_a NULL, [n][n]) — acts = t·s is
+ *                     re-formed from the gate halves ts [B][2n][L] the fused forward saved
+ * kind 0 = in_layer + cond_layer, 1 = res_skip.  fst_wn_wgrad_ok: 1 when the shape is served (L % 32 == 0, n < 128, h <= 32 and for
+ * kind 0 dil % 4 == 0), else the caller uses fst_conv_wgrad.  workspace: fst_wn_wgrad_workspace_floats(...) floats, written. */
+int fst_wn_wgrad_ok(int kind, int B, int L, int n, int h, int dil);
+int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, int h, int last);
+int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0, int64_t u0_bs, float* dw_in, float* dw_cond, float* workspace,
+                    int64_t workspace_floats, int B, int L, int n, int h, int dil, int64_t numel_a, void* stream);
+int fst_wn_wgrad_rs(const float* d_a /* NULL iff last */, const float* d_out, const float* ts, float* dw_rs, float* workspace,
+                    int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a, void* stream);
+
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */
 int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,

@@ -199,3 +199,34 @@ def test_joint_step_gradients_at_batch_32(arithmetic):
     gen = torch.Generator().manual_seed(seed + 1)
     batch = (_pair(gen, Bq, 1, L, 4), _pair(gen, Bq, 1, L, 4))
     _check_step(*_step_both(js, tr, batch, (L // 8, L // 16)), tr, f"B=32 L={L} {arithmetic}", math=arithmetic)
+
+
+@pytest.mark.parametrize("n,h,Bq,L,dil", [(120, 25, 256, 512, 4), (120, 25, 256, 512, 128), (120, 25, 64, 1024, 16),
+                                          (8, 3, 3, 64, 4), (33, 31, 2, 96, 8), (127, 32, 2, 128, 4), (16, 16, 5, 32, 8),
+                                          (120, 25, 1, 32, 4)])      # one tile in all: most workgroups have nothing to do
+def test_time_as_k_weight_gradient_kernels(n, h, Bq, L, dil):
+    """csrc/wn_wgrad.hip (time as the MFMA reduction index, per-workgroup slabs added in a fixed order) against fp64 einsums:
+    in_layer + cond_layer (three dilated taps, the 385th k-row on the VALU) and res_skip with acts = t·s re-formed from the saved
+    halves (both row counts); twice, bit for bit the same (no atomics)."""
+    g = torch.Generator(device=DEV).manual_seed(n * 7 + L + dil)
+    assert ops.wn_wgrad_ok(0, Bq, L, n, h, dil) and ops.wn_wgrad_ok(1, Bq, L, n, h, dil)
+    assert not ops.wn_wgrad_ok(0, Bq, L, n, h, 2) and not ops.wn_wgrad_ok(0, Bq, L + 4, n, h, dil)
+    a, dgd = _rnd(g, Bq, n, L), _rnd(g, Bq, 2 * n, L)
+    u0 = _rnd(g, Bq, 2 * h, L)[:, :h]                                   # a channel-slice view, as the flow passes it
+    dw_in, dw_cond = torch.full((2 * n, n, 3), 7.0, device=DEV), torch.full((2 * n, h, 1), 7.0, device=DEV)
+    ops.wn_wgrad_in(dgd, a, u0, dw_in, dw_cond, n, h, dil)
+    ap = F.pad(a.double(), (dil, dil))
+    want = torch.stack([torch.einsum("bmt,bct->mc", dgd.double(), ap[:, :, k * dil: k * dil + L]) for k in range(3)], dim=2)
+    assert_close(dw_in, want, 1e-4, "in_layer dW")
+    assert_close(dw_cond[:, :, 0], torch.einsum("bmt,bct->mc", dgd.double(), u0.double()), 1e-4, "cond_layer dW")
+    again_in, again_cond = torch.empty_like(dw_in), torch.empty_like(dw_cond)
+    ops.wn_wgrad_in(dgd, a, u0, again_in, again_cond, n, h, dil)
+    assert torch.equal(again_in, dw_in) and torch.equal(again_cond, dw_cond)
+    ts = _rnd(g, Bq, 2 * n, L)
+    d_a, d_out = _rnd(g, Bq, n, L), _rnd(g, Bq, n, L)
+    acts = ts[:, :n].double() * ts[:, n:].double()
+    for last in (False, True):
+        dw = torch.full((n if last else 2 * n, n, 1), 7.0, device=DEV)
+        ops.wn_wgrad_rs(None if last else d_a, d_out, ts, dw, last, n)
+        dy = d_out if last else torch.cat([d_a, d_out], 1)
+        assert_close(dw[:, :, 0], torch.einsum("bmt,bct->mc", dy.double(), acts), 1e-4, f"res_skip dW (last={last})")
