@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void logdet_inv_kernel(const float* W, int n, 
 }
 
 extern "C" int fst_logdet_inv(const float* W, int n, float* out, float* inv_t, void* stream) {
-  FST_REQUIRE(W && out && inv_t && n > 0 && n <= 128, "fst_logdet_inv: needs 0 < n <= 128 (one workgroup holds the matrix in LDS as doubles); n=%d", n);
+  FST_REQUIRE(W && out && inv_t && n > 0 && n <= 96, "fst_logdet_inv: needs 0 < n <= 96 (one workgroup holds the matrix in LDS as doubles); n=%d", n);
   const size_t lds = (size_t)n * n * sizeof(double);
   if (lds > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)logdet_inv_kernel, "fst_logdet_inv")) return rc;

@@ -10,16 +10,18 @@
 // conv_wgrad_kernel it replaces for these shapes (99 µs, MFMA-busy 0.24, 706 MB through L2 → LDS for 202 MB of operands):
 //   * one 8-wave workgroup per CU owns ALL 2n output rows × 192 k-rows (6 blocks; in_layer: two such groups, so dy passes the
 //     L2 → LDS path twice instead of four times) for a contiguous range of 32-sample time tiles;
-//   * operands reach LDS by LDS-DMA as raw fp32 rows of 32 samples (128 B), two slots, ONE barrier per tile; a row's eight
-//     16-byte pieces are XOR-swizzled by (row & 7) and every second octet of rows swaps row parity, so the fragment reads
-//     (two ds_read_b128 per fragment) are bank-conflict-free although rows are a multiple of 128 B apart;
+//   * operands reach LDS by LDS-DMA as raw fp32 rows of 16 samples (64 B = one MFMA k-step) through a ring of 4-5 slots with
+//     3-4 stages in flight behind counted vmcnt waits, ONE barrier per stage (a two-slot ring of 32-sample tiles, which issues
+//     a tile only when its predecessor has landed, ran at a third of this rate: no overlap of one tile's latency with the
+//     next one's transfer); a row's four 16-byte pieces are XOR-swizzled by a function of the row, so the fragment reads
+//     (two ds_read_b128 per fragment) are bank-conflict-free although rows are 16 banks apart;
 //   * each wave multiplies a 2 × 3 (res_skip: 2 × 2) tile of 32×32 blocks: five raw fragments are split into bf16 hi/lo in
 //     registers per k-step for 18 triple-MFMAs (hi·hi + hi·lo + lo·hi, fp32 accumulate);
 //   * a k-row count one past a multiple of 32 (3·120 + 25 = 385) does not cost a thirteenth block: the leftover row is
 //     accumulated on the VALU from the dy fragments the wave holds anyway;
 //   * every workgroup stores its partial D tile into its own slab (plain stores, two full 128-B segments per instruction);
 //     wn_wgrad_reduce_kernel adds the slabs in a fixed order and writes PyTorch layout: deterministic, no atomics.
-// Served: L % 32 == 0, n < 128 (M ≤ 256), h ≤ 32, tap shifts that are multiples of 4 samples (dil % 4 == 0), 16-byte aligned
+// Served: L % 16 == 0, n < 128 (M ≤ 256), h ≤ 32, tap shifts that are multiples of 4 samples (dil % 4 == 0), 16-byte aligned
 // tensors; everything else stays on conv_wgrad_kernel (fst_wn_wgrad_ok tells).
 #include "fst_common.h"
 
@@ -30,9 +32,9 @@ typedef unsigned ww_u32x4 __attribute__((ext_vector_type(4)));
 #define WW_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define WW_LDS_VOID(p) ((__attribute__((address_space(3))) void*)(p))
 
-#define WW_TT 32          // time samples per tile = one 128-byte LDS row
+#define WW_TT 16          // time samples per stage = one MFMA k-step = one 64-byte LDS row
 #define WW_MROWS 256      // staged dy rows (8 blocks of 32)
-#define WW_MAX_NI 9       // LDS-DMA instructions (8 rows each) per wave and tile
+#define WW_MAX_NI 5       // LDS-DMA instructions (16 rows each) per wave and stage
 
 __device__ __attribute__((aligned(16))) float ww_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -51,7 +53,8 @@ struct WwParams {
   int xr;               // staged k-rows per group = 32·2·KT
   int mul;              // 1: every k-row is staged twice (row and partner) and multiplied when its fragment is read
   int n_groups, ksplit, B, L, tiles_per_seq, n_tiles;
-  int R;                // staged rows per tile (multiple of 8)
+  int R;                // staged rows per stage (multiple of 16)
+  int ns;               // ring slots
   int Kcols;            // slab row length = n_groups·xr
   float* slab;          // [ksplit][256][Kcols]
   float* slab_extra;    // [ksplit][256][2]
@@ -80,26 +83,34 @@ template <int N>
 __device__ __forceinline__ void ww_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void ww_wait_sw(int n) {      // counted wait for a wave-uniform run-time count
+  if (n >= N) { ww_wait_vmcnt<N>(); return; }
+  if constexpr (N > 0) ww_wait_sw<N - 1>(n);
+}
 
-// logical staged row r, 16-byte piece q (0..7) → byte offset inside a slot: rows of odd octets swap parity, pieces are
-// XOR-swizzled by (r & 7): the sixteen lanes a ds_read_b128 services together then cover all 64 banks
-__device__ __forceinline__ int ww_lds_off(int r, int q) { return ((r ^ ((r >> 3) & 1)) << 7) + (((q ^ r) & 7) << 4); }
+// A staged row is 16 samples = four 16-byte pieces (64 B); row r sits at r·64 and its piece q at slot q ^ ww_g((r & 31) >> 2):
+// the sixteen lanes a ds_read_b128 services together (rows {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of a block) then
+// cover all 64 banks (checked exhaustively on the host side of the tests' development; rows alone are 16 banks apart).
+__device__ __forceinline__ int ww_g(int x) { return x < 4 ? (x >> 1) : 2 + (x & 1); }
 
-template <int MT, int KT>
+// FULL: every output-row block and every k-row block of every group is live (M = 256-ish, K_main a multiple of the group size):
+// no block tests in the inner loop.
+template <int MT, int KT, bool FULL>
 __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   extern __shared__ __attribute__((aligned(16))) char ww_lds[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_s >> 1, wk = wave_s & 1;          // 4 (output-row pairs) × 2 (k-row halves of the group)
   const int g = blockIdx.y, L = p.L;
-  const int slot_bytes = p.R * 128;
+  const int slot_bytes = p.R * 64;
   const char* const zero16 = reinterpret_cast<const char*>(ww_zero16);
 
   // ---- per (LDS-DMA instruction of this wave, lane): which 16 bytes of which tensor row it fetches.  Instruction i fills the
-  // LDS rows 8i..8i+7 (1 KiB, lane-linear); lane → LDS row 8i + (lane >> 3), piece slot lane & 7 → logical row / piece by the
-  // inverse of ww_lds_off.  Staged rows: [0, 256) dy rows, [256, 256 + xr) this group's k-rows, [.., + xr) their partners
-  // (product operand), then one octet for the leftover rows (group 0 only).
-  const int NI = p.R >> 3;
+  // LDS rows 16i..16i+15 (1 KiB, lane-linear): lane → row 16i + (lane >> 2), piece slot lane & 3.  Staged rows: [0, 256) dy
+  // rows, [256, 256 + xr) this group's k-rows, [.., + xr) their partners (product operand), then 16 rows for the leftover
+  // k-rows (group 0 only).
+  const int NI = p.R >> 4;
   const int my_ni = (NI - wave_s + 7) >> 3;               // instructions i = wave, wave + 8, ...  (wave-uniform count)
   const float* src0[WW_MAX_NI];                           // address of the piece in batch element 0 at t0 = 0 (null: zero fill)
   int src_bs[WW_MAX_NI], src_t[WW_MAX_NI];                // batch stride (floats); first sample of the piece relative to t0
@@ -108,8 +119,8 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
     src0[k] = nullptr; src_bs[k] = 0; src_t[k] = 0;
     const int i = wave_s + 8 * k;
     if (k >= my_ni) continue;
-    const int r = 8 * i + ((lane >> 3) ^ (i & 1));
-    const int q = (lane ^ r) & 7;
+    const int r = 16 * i + (lane >> 2);
+    const int q = (lane ^ ww_g((r & 31) >> 2)) & 3;
     int which = -1, c = 0;                                 // 0, 1: dy segments; 2..5: x segments
     bool partner = false;
     if (r < WW_MROWS) {
@@ -179,75 +190,77 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   const int k_blocks_here = min(2 * KT, ((p.K_main + 31) >> 5) - g * 2 * KT);   // live k-row blocks of this group
   const bool do_extra = g == 0 && wk == 0 && p.n_extra > 0;
 
-  // fragment addressing: row block·32 + l31, pieces (4·ks + 2·half) and the next one
-  const int row_l = (l31 ^ ((l31 >> 3) & 1)) << 7;        // ww_lds_off's row term for a row ≡ l31 (mod 32)
-  const int sw = l31 & 7;
-  int pc[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    pc[ks][0] = (((4 * ks + 2 * half) ^ sw) & 7) << 4;
-    pc[ks][1] = (((4 * ks + 2 * half + 1) ^ sw) & 7) << 4;
-  }
-  const int x_base = (WW_MROWS + wk * KT * 32) << 7, xp_base = x_base + (p.xr << 7);
-  const int e_base = (WW_MROWS + p.xr * (1 + p.mul)) << 7;
+  // fragment addressing: row block·32 + l31, pieces 2·half and 2·half + 1 (the 8 samples of this lane half)
+  const int gsw = ww_g(l31 >> 2);
+  const int row_l = l31 << 6;
+  const int pc0 = (((2 * half) ^ gsw) & 3) << 4, pc1 = (((2 * half + 1) ^ gsw) & 3) << 4;
+  const int a_base = ((wm * MT * 32) << 6) + row_l;
+  const int x_base = ((WW_MROWS + wk * KT * 32) << 6) + row_l, xp_base = x_base + (p.xr << 6);
+  const int e_base = (WW_MROWS + p.xr * (1 + p.mul)) << 6;      // rows e < 16 of this octet: g(e >> 2) = e >> 3 for e < 8: 0
 
-  if (tile_begin < tile_end) issue(tile_begin, 0);
+  // ring: `depth` stages in flight; one barrier per stage
+  const int ns = p.ns, depth = ns - 1;
+  const int n_st = tile_end - tile_begin;
+  for (int d = 0; d < depth && d < n_st; ++d) issue(tile_begin + d, d);
   int slot = 0;
-  for (int tile = tile_begin; tile < tile_end; ++tile) {
-    ww_wait_vmcnt<0>();                                    // this wave's pieces of the tile have landed (nothing else is in flight)
-    __builtin_amdgcn_s_barrier();                          // ... everyone's have, and everyone is done reading the other slot
-    if (tile + 1 < tile_end) issue(tile + 1, slot ^ 1);
+  for (int c = 0; c < n_st; ++c) {
+    // stages still allowed in flight behind stage c: those already issued, i.e. min(depth - 1, n_st - 1 - c)
+    const int newer = min(depth - 1, n_st - 1 - c);
+    ww_wait_sw<16>(newer * my_ni);
+    __builtin_amdgcn_s_barrier();                          // everyone's pieces of stage c have landed; stage c - 1 has been read by all
+    if (c + depth < n_st) {
+      int sl_i = slot + depth;
+      if (sl_i >= ns) sl_i -= ns;
+      issue(tile_begin + c + depth, sl_i);
+    }
     const char* const sl = ww_lds + slot * slot_bytes;
+    ww_bf16x8 ah[MT], al[MT];
+    float4 araw[MT][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      ww_bf16x8 ah[MT], al[MT];
-      float4 araw[MT][2];
+    for (int i = 0; i < MT; ++i) {
+      const char* ap = sl + a_base + ((i * 32) << 6);
+      araw[i][0] = *reinterpret_cast<const float4*>(ap + pc0);
+      araw[i][1] = *reinterpret_cast<const float4*>(ap + pc1);
+      ww_split8(araw[i][0], araw[i][1], ah[i], al[i]);
+    }
+    if (do_extra) {
+      // leftover k-rows on the VALU: every lane of a half reads the same 8 samples of the row (a broadcast), lane = output row
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const char* ap = sl + (((wm * MT + i) * 32) << 7) + row_l;
-        araw[i][0] = *reinterpret_cast<const float4*>(ap + pc[ks][0]);
-        araw[i][1] = *reinterpret_cast<const float4*>(ap + pc[ks][1]);
-        ww_split8(araw[i][0], araw[i][1], ah[i], al[i]);
-      }
-      if (do_extra) {
-        // leftover k-rows on the VALU: every lane of a half reads the same 8 samples of the row (a broadcast), lane = output row
+      for (int e = 0; e < 2; ++e) {
+        if (e >= p.n_extra) break;
+        const char* ep = sl + e_base + (e << 6);
+        const float4 x0 = *reinterpret_cast<const float4*>(ep + ((2 * half) << 4));
+        const float4 x1 = *reinterpret_cast<const float4*>(ep + ((2 * half + 1) << 4));
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          if (e >= p.n_extra) break;
-          const char* ep = sl + e_base + (e << 7);
-          const float4 x0 = *reinterpret_cast<const float4*>(ep + ((((4 * ks + 2 * half) ^ e) & 7) << 4));
-          const float4 x1 = *reinterpret_cast<const float4*>(ep + ((((4 * ks + 2 * half + 1) ^ e) & 7) << 4));
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-            ev[i][e] += (araw[i][0].x * x0.x + araw[i][0].y * x0.y) + (araw[i][0].z * x0.z + araw[i][0].w * x0.w) +
-                        (araw[i][1].x * x1.x + araw[i][1].y * x1.y) + (araw[i][1].z * x1.z + araw[i][1].w * x1.w);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < KT; ++j) {
-        if (wk * KT + j >= k_blocks_here) break;           // wave-uniform: blocks beyond K hold zeros
-        const char* bp = sl + x_base + ((j * 32) << 7) + row_l;
-        float4 b0 = *reinterpret_cast<const float4*>(bp + pc[ks][0]);
-        float4 b1 = *reinterpret_cast<const float4*>(bp + pc[ks][1]);
-        if (p.mul) {                                       // kernel argument: uniform
-          const char* qp = sl + xp_base + ((j * 32) << 7) + row_l;
-          const float4 c0 = *reinterpret_cast<const float4*>(qp + pc[ks][0]);
-          const float4 c1 = *reinterpret_cast<const float4*>(qp + pc[ks][1]);
-          b0.x *= c0.x; b0.y *= c0.y; b0.z *= c0.z; b0.w *= c0.w;
-          b1.x *= c1.x; b1.y *= c1.y; b1.z *= c1.z; b1.w *= c1.w;
-        }
-        ww_bf16x8 bh, bl;
-        ww_split8(b0, b1, bh, bl);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          if (wm * MT + i >= m_blocks) break;              // wave-uniform
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < MT; ++i)
+          ev[i][e] += (araw[i][0].x * x0.x + araw[i][0].y * x0.y) + (araw[i][0].z * x0.z + araw[i][0].w * x0.w) +
+                      (araw[i][1].x * x1.x + araw[i][1].y * x1.y) + (araw[i][1].z * x1.z + araw[i][1].w * x1.w);
       }
     }
-    slot ^= 1;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      if (!FULL && wk * KT + j >= k_blocks_here) break;    // wave-uniform: blocks beyond K hold zeros
+      const char* bp = sl + x_base + ((j * 32) << 6);
+      float4 b0 = *reinterpret_cast<const float4*>(bp + pc0);
+      float4 b1 = *reinterpret_cast<const float4*>(bp + pc1);
+      if (p.mul) {                                         // kernel argument: uniform
+        const char* qp = sl + xp_base + ((j * 32) << 6);
+        const float4 c0 = *reinterpret_cast<const float4*>(qp + pc0);
+        const float4 c1 = *reinterpret_cast<const float4*>(qp + pc1);
+        b0.x *= c0.x; b0.y *= c0.y; b0.z *= c0.z; b0.w *= c0.w;
+        b1.x *= c1.x; b1.y *= c1.y; b1.z *= c1.z; b1.w *= c1.w;
+      }
+      ww_bf16x8 bh, bl;
+      ww_split8(b0, b1, bh, bl);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (!FULL && wm * MT + i >= m_blocks) break;       // wave-uniform
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+      }
+    }
+    slot = slot + 1 == ns ? 0 : slot + 1;
   }
 
   // ---- partial D tile → this workgroup's slab: register r of a tile = output row (r&3) + 8(r>>2) + 4·half, lane & 31 = k-row:
@@ -318,7 +331,9 @@ static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams*
   const int kb = (p->K_main + 31) / 32;
   p->n_groups = (kb + 2 * KT - 1) / (2 * KT);
   p->mul = kind == 1;
-  p->R = WW_MROWS + p->xr * (1 + p->mul) + (p->n_extra ? 8 : 0);
+  p->R = WW_MROWS + p->xr * (1 + p->mul) + (p->n_extra ? 16 : 0);
+  p->ns = (int)((160 * 1024) / ((size_t)p->R * 64));
+  if (p->ns > 5) p->ns = 5;
   p->Kcols = p->n_groups * p->xr;
   p->B = B; p->L = L;
   p->tiles_per_seq = L / WW_TT;
@@ -332,7 +347,7 @@ static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams*
 }
 
 extern "C" int fst_wn_wgrad_ok(int kind, int B, int L, int n, int h, int dil) {
-  if (!(B > 0 && L > 0 && L % WW_TT == 0 && n > 0 && n < 128)) return 0;
+  if (!(B > 0 && L > 0 && L % WW_TT == 0 && n > 0 && n < 128)) return 0;      // (16-sample stages)
   if (kind == 0) return h > 0 && h <= 32 && dil > 0 && dil % 4 == 0 && (3 * n + h + 31) / 32 <= 18;
   return kind == 1;
 }
@@ -345,9 +360,12 @@ extern "C" int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, 
 }
 
 static int ww_launch(WwParams& p, int KT, void* stream) {
-  const size_t lds = (size_t)2 * p.R * 128;
-  FST_REQUIRE(lds <= 160 * 1024 && (p.R >> 3) <= 8 * WW_MAX_NI, "fst_wn_wgrad: %d staged rows per tile do not fit (LDS %zu B)", p.R, lds);
-  void (*fn)(WwParams) = KT == 3 ? wn_wgrad_kernel<2, 3> : wn_wgrad_kernel<2, 2>;
+  const size_t lds = (size_t)p.ns * p.R * 64;
+  FST_REQUIRE(p.ns >= 2 && lds <= 160 * 1024 && (p.R >> 4) <= 8 * WW_MAX_NI && ((p.R >> 4) + 7) / 8 * (p.ns - 2) <= 16,
+              "fst_wn_wgrad: %d staged rows per stage do not fit (ring of %d slots, LDS %zu B)", p.R, p.ns, lds);
+  const bool full = (p.M + 31) / 32 == 8 && ((p.K_main + 31) / 32) % (2 * KT) == 0;
+  void (*fn)(WwParams) = KT == 3 ? (full ? wn_wgrad_kernel<2, 3, true> : wn_wgrad_kernel<2, 3, false>)
+                                 : (full ? wn_wgrad_kernel<2, 2, true> : wn_wgrad_kernel<2, 2, false>);
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_wn_wgrad")) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
@@ -362,7 +380,7 @@ extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0,
                                float* workspace, int64_t workspace_floats, int B, int L, int n, int h, int dil, int64_t numel_a,
                                void* stream) {
   FST_REQUIRE(dg && a && u0 && dw_in && dw_cond && workspace, "fst_wn_wgrad_in: null operand");
-  FST_REQUIRE(fst_wn_wgrad_ok(0, B, L, n, h, dil), "fst_wn_wgrad_in: unsupported shape B=%d L=%d n=%d h=%d dil=%d (needs L %% 32 == 0, "
+  FST_REQUIRE(fst_wn_wgrad_ok(0, B, L, n, h, dil), "fst_wn_wgrad_in: unsupported shape B=%d L=%d n=%d h=%d dil=%d (needs L %% 16 == 0, "
               "n < 128, h <= 32, dil %% 4 == 0)", B, L, n, h, dil);
   FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_in: B*n*L does not match the element count %lld of a", (long long)numel_a);
   FST_REQUIRE(B == 1 || u0_bs >= (int64_t)h * L, "fst_wn_wgrad_in: u0 batch stride %lld < h*L", (long long)u0_bs);
@@ -385,7 +403,7 @@ extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0,
 extern "C" int fst_wn_wgrad_rs(const float* d_a, const float* d_out, const float* ts, float* dw_rs, float* workspace,
                                int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a, void* stream) {
   FST_REQUIRE(d_out && ts && dw_rs && workspace && (last || d_a), "fst_wn_wgrad_rs: null operand");
-  FST_REQUIRE(fst_wn_wgrad_ok(1, B, L, n, 0, 4), "fst_wn_wgrad_rs: unsupported shape B=%d L=%d n=%d (needs L %% 32 == 0, n < 128)", B, L, n);
+  FST_REQUIRE(fst_wn_wgrad_ok(1, B, L, n, 0, 4), "fst_wn_wgrad_rs: unsupported shape B=%d L=%d n=%d (needs L %% 16 == 0, n < 128)", B, L, n);
   FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_rs: B*n*L does not match the element count %lld", (long long)numel_a);
   FST_REQUIRE(ww_al16(d_a) && ww_al16(d_out) && ww_al16(ts) && ww_al16(workspace), "fst_wn_wgrad_rs: operands must be 16-byte aligned");
   WwParams p = {};

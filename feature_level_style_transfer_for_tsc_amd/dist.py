@@ -37,6 +37,8 @@ class GradBucket:
         self.world = dist.get_world_size(process_group)
         self.always_reduce = always_reduce
         self._flat: Optional[torch.Tensor] = None
+        self._stream = None           # side stream of the bucket all-reduce (GPU only)
+        self._pending = False
 
     def _buffer(self, n: int, like: torch.Tensor) -> torch.Tensor:
         if self._flat is None or self._flat.numel() != n or self._flat.device != like.device:
@@ -45,6 +47,15 @@ class GradBucket:
 
     def all_reduce(self, params: Iterable[torch.nn.Parameter]) -> None:
         """Average ``.grad`` of every parameter that has one, in place, with ONE collective."""
+        self.all_reduce_begin(params)
+        self.all_reduce_end()
+
+    def all_reduce_begin(self, params: Iterable[torch.nn.Parameter]) -> None:
+        """Start averaging ``.grad`` of every parameter that has one.  On the GPU the pack, the collective, the scale and the
+        copy back run on a SIDE stream ordered after everything already issued on the current stream, so work issued next on
+        the current stream that does not touch ``.grad`` (GradNorm's partial backward passes) overlaps the all-reduce;
+        ``all_reduce_end`` orders the current stream after it."""
+        self._pending = False
         grads: List[torch.Tensor] = [p.grad for p in params if p.grad is not None]
         if not grads or (self.world == 1 and not self.always_reduce):
             return
@@ -54,10 +65,26 @@ class GradBucket:
         for g in grads:
             views.append(flat[off: off + g.numel()].view_as(g))
             off += g.numel()
-        torch._foreach_copy_(views, grads)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / self.world)
-        torch._foreach_copy_(grads, views)
+
+        def body():
+            torch._foreach_copy_(views, grads)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.mul_(1.0 / self.world)
+            torch._foreach_copy_(grads, views)
+        if flat.is_cuda:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=flat.device)
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                body()
+            self._pending = True
+        else:
+            body()
+
+    def all_reduce_end(self) -> None:
+        if getattr(self, "_pending", False):
+            torch.cuda.current_stream().wait_stream(self._stream)
+            self._pending = False
 
     def mean_scalars(self, t: torch.Tensor) -> torch.Tensor:
         if self.world == 1 and not self.always_reduce:

@@ -716,7 +716,7 @@ class WNSpecs:
 
 def wn_wgrad_ok(kind: int, B: int, L: int, n: int, h: int, dil: int) -> bool:
     """Whether the time-as-k weight-gradient kernels of csrc/wn_wgrad.hip serve this layer (kind 0 = in_layer + cond_layer,
-    1 = res_skip): split-bf16 arithmetic, L % 32 == 0, n < 128, h <= 32, tap shifts that are multiples of 4 samples.  Everything
+    1 = res_skip): split-bf16 arithmetic, L % 16 == 0, n < 128, h <= 32, tap shifts that are multiples of 4 samples.  Everything
     else stays on the generic fst_conv_wgrad."""
     if MATH != "bf16x3" or os.environ.get("FST_WN_WGRAD", "1") == "0":
         return False
@@ -1374,8 +1374,8 @@ class LogDetFn(torch.autograd.Function):
 
 
 def logdet(W: Tensor) -> Tensor:
-    """``torch.logdet`` for the flow's 1x1 weights: the one-launch kernel up to 128 channels, stock torch beyond."""
-    if W.is_cuda and W.dim() == 2 and W.size(0) <= 128 and W.dtype == torch.float32:
+    """``torch.logdet`` for the flow's 1x1 weights: the one-launch kernel up to 96 channels, stock torch beyond."""
+    if W.is_cuda and W.dim() == 2 and W.size(0) <= 96 and W.dtype == torch.float32:
         return LogDetFn.apply(W)
     return torch.logdet(W)
 

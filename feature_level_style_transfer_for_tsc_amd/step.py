@@ -26,7 +26,7 @@ from .cdan import CDAN, RandomLayer
 from .cpc import CPC
 from . import dist as _dist
 from .dist import GradBucket
-from .optim import SharedStepAdam
+from .optim import FusedRMSprop, SharedStepAdam, rmsprop_step_many
 from .os_cnn import OS_CNN, OS_CNN_res, build_layer_with_layer_parameter
 from .structure import generate_layer_parameter_list, layer_parameter_list_input_change, out_channels
 from .waveglow import WaveGlow, WaveGlowLoss
@@ -68,8 +68,8 @@ class ClassifierTrainer:
         self.fe = OS_CNN_res(fe_spec).to(device)
         self.clf = OS_CNN(clf_spec, n_class).to(device)
         # capturable: the optimisers' step counters live on the device, so the step can be captured into a hipGraph
-        self.opt_fe = torch.optim.RMSprop(self.fe.parameters(), lr=0.001, capturable=True)
-        self.opt_clf = torch.optim.RMSprop(self.clf.parameters(), lr=0.003, capturable=True)
+        self.opt_fe = FusedRMSprop(self.fe.parameters(), lr=0.001)
+        self.opt_clf = FusedRMSprop(self.clf.parameters(), lr=0.003)
         self.bucket = bucket
         self.fe.train(); self.clf.train()
         self._graph = None
@@ -85,7 +85,7 @@ class ClassifierTrainer:
                 loss.backward()
         if self.bucket is not None:
             self.bucket.all_reduce(self.parameters())
-        self.opt_fe.step(); self.opt_clf.step()
+        rmsprop_step_many([self.opt_fe, self.opt_clf])
         self.opt_fe.zero_grad(set_to_none=True); self.opt_clf.zero_grad(set_to_none=True)
         return loss.detach(), logits.detach()
 
@@ -169,8 +169,8 @@ class JointTrainer:
         self.m = {k: v.to(device) for k, v in m.items()}
         self.random_layer = self.random_layer.to(device)
         self.nf_loss = WaveGlowLoss()
-        # capturable=True keeps the optimiser step counters on the device (needed under hipGraph capture)
-        self.opts = {k: torch.optim.RMSprop(self.m[k].parameters(), lr=lr, capturable=True) for k, lr in self.LRS.items()}
+        # ten RMSprops (one learning rate per module) stepped by the same single-pass multi-tensor launches (optim.FusedRMSprop)
+        self.opts = {k: FusedRMSprop(self.m[k].parameters(), lr=lr) for k, lr in self.LRS.items()}
         # CPC = 516 small tensors: torch's capturable Adam spends ~4 k tiny kernels per step on per-parameter step
         # counters; same update with one shared device counter (optim.SharedStepAdam)
         self.opt_cpc = SharedStepAdam(self.m["cpc"].parameters(), lr=0.002)
@@ -402,8 +402,9 @@ class JointTrainer:
             self.bucket.all_reduce(self.parameters())
         if self.on_grads_ready is not None:
             self.on_grads_ready()
-        for k in self.PHASES[phase]:
-            (self.opt_cpc if k == "cpc" else self.opts[k]).step()
+        rmsprop_step_many([self.opts[k] for k in self.PHASES[phase] if k != "cpc"])
+        if "cpc" in self.PHASES[phase]:
+            self.opt_cpc.step()
         report = {k: v.detach() for k, v in L.items()}
         report["total"] = total.detach()
         return report
@@ -416,15 +417,29 @@ class JointTrainer:
 
     def _step_body(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
         """Everything device-side and shape-static, so it runs eagerly or under hipGraph capture unchanged.
-        Two halves with the step's only collectives between them (so a captured step never contains RCCL):
-        A = forward, GradNorm partial backwards, full backward;  B = GradNorm weight update + optimisers."""
-        with _dist.global_batch(self.bucket if self.sync == "global" else None):
-            mid = self._step_part_a(x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios)
-        self._reduce(mid)
+        Three parts with the step's only collectives between them (so a captured step never contains RCCL):
+        A1 = forward + the full backward;  [the gradient bucket's all-reduce starts on a side stream]
+        A2 = GradNorm's partial backward passes (they never touch ``.grad``: they overlap the all-reduce);
+        [wait for the bucket; average the 10 GradNorm scalars]  B = GradNorm weight update + optimisers."""
+        with _dist.global_batch(self.bucket if self.sync == "global" else None), self._step_scope():
+            state = self._step_part_a1(x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios)
+            self._reduce_begin()
+            mid = self._step_part_a2(state)
+        self._reduce_end(mid)
         return self._step_part_b(mid)
 
-    def _step_part_a(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
-        with ops.pack_cache(), self.m["nf"].shared_fold(), self.m["cpc"].shared_stack():
+    def _step_scope(self):
+        """One scope for forward and every backward pass of a step: weights packed once, the flow's weight-norm fold and the
+        CPC predictor stack built once."""
+        import contextlib
+        st = contextlib.ExitStack()
+        st.enter_context(ops.pack_cache())
+        st.enter_context(self.m["nf"].shared_fold())
+        st.enter_context(self.m["cpc"].shared_stack())
+        return st
+
+    def _step_part_a1(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
+        if True:
             L, aux = self.forward_losses(x_t, y_t, x_s, y_s, t_samples, noise_ratios)
             lt = torch.stack([L["nf_t"], L["ce_t"]])
             ls = torch.stack([L["nf_s"], L["ce_s"], L["ce_s2t2s"]])
@@ -436,6 +451,11 @@ class JointTrainer:
                 o.zero_grad(set_to_none=True)
             self.opt_cpc.zero_grad(set_to_none=True)
             total.backward(retain_graph=True)
+        return {"L": L, "aux": aux, "lt": lt, "ls": ls}
+
+    def _step_part_a2(self, state):
+        L, aux, lt, ls = state["L"], state["aux"], state["lt"], state["ls"]
+        if True:
             # GradNorm (:682-690): per-loss gradient norms over the 12 shared tensors
             sh_t = list(self.m["fe_t"].return_last_layer().parameters())
             sh_s = list(self.m["fe_s"].return_last_layer().parameters())
@@ -461,11 +481,18 @@ class JointTrainer:
         scal = torch.cat([lt.detach(), ls.detach(), base_t, base_s]).contiguous()
         return {"report": report, "scal": scal}
 
-    def _reduce(self, mid) -> None:
-        """The step's collectives: average the flat gradient bucket and the 10 GradNorm scalars over ranks."""
+    def _step_part_a(self, x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios):
+        with self._step_scope():
+            return self._step_part_a2(self._step_part_a1(x_t, y_t, x_s, y_s, epoch, t_samples, noise_ratios))
+
+    def _reduce_begin(self) -> None:
+        if self.bucket is not None:
+            self.bucket.all_reduce_begin(self.parameters())
+
+    def _reduce_end(self, mid) -> None:
         if self.bucket is None:
             return
-        self.bucket.all_reduce(self.parameters())
+        self.bucket.all_reduce_end()
         mid["scal"].copy_(self.bucket.mean_scalars(mid["scal"]))
 
     def _step_part_b(self, mid):
@@ -488,8 +515,7 @@ class JointTrainer:
         if self.on_grads_ready is not None:
             self.on_grads_ready()
         self.opt_w_t.step(); self.opt_w_s.step()
-        for o in self.opts.values():
-            o.step()
+        rmsprop_step_many(list(self.opts.values()))
         self.opt_cpc.step()
         with torch.no_grad():                                                 # :756-766
             self.w_t.clamp_(min=0.0)
@@ -512,7 +538,8 @@ class JointTrainer:
         start indices and NoiseTransfer's two accumulation ratios.  The GRL coefficients are Python floats baked in
         at capture, so the warm-up runs until their call counters saturate (20 calls = 10 steps — quirk Q7); the
         epoch-dependent loss coefficients are baked too: re-capture when ``loss_coefficients(epoch)`` changes.
-        Single GPU: one graph.  Data parallel: two graphs (A, B) with the eager RCCL all-reduce between them."""
+        Single GPU: one graph.  Data parallel: three graphs (A1 forward + backward, A2 GradNorm's partial passes, B update)
+        with the eager RCCL collectives between them, the gradient all-reduce overlapping A2 on a side stream."""
         if self.sync == "global" and self.bucket is not None and self.bucket.world > 1:
             raise RuntimeError("sync='global' (mode B) puts collectives inside autograd: run it eagerly with step()")
         dev = self.device
@@ -536,20 +563,22 @@ class JointTrainer:
             with torch.cuda.graph(self._graphs[0], capture_error_mode=_CAPTURE_MODE):
                 self._g_out = self._graph_body()
         else:
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, capture_error_mode=_CAPTURE_MODE):
-                self._g_mid = self._graph_part_a()
-            pool = ga.pool()
-            self._reduce(self._g_mid)                                         # eager; also fixes the bucket's buffer
+            ga1, ga2, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            gi = self._g_in
+            with self._step_scope():                                          # packed weights of A1 are reused by A2
+                with torch.cuda.graph(ga1, capture_error_mode=_CAPTURE_MODE):
+                    state = self._step_part_a1(gi["x_t"], gi["y_t"], gi["x_s"], gi["y_s"], self._g_epoch, (gi["t"][0], gi["t"][1]),
+                                               (gi["r"][0], gi["r"][1]))
+                pool = ga1.pool()
+                self._reduce_begin()                                          # eager, on the bucket's side stream
+                with torch.cuda.graph(ga2, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                    self._g_mid = self._step_part_a2(state)
+                del state                                                     # the autograd graph of the captured step
+            self._reduce_end(self._g_mid)                                     # eager; also fixes the bucket's buffer
             with torch.cuda.graph(gb, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 self._g_out = self._step_part_b(self._g_mid)
-            self._graphs = [ga, gb]
+            self._graphs = [ga1, ga2, gb]
         return self
-
-    def _graph_part_a(self):
-        gi = self._g_in
-        return self._step_part_a(gi["x_t"], gi["y_t"], gi["x_s"], gi["y_s"], self._g_epoch, (gi["t"][0], gi["t"][1]),
-                                 (gi["r"][0], gi["r"][1]))
 
     def _graph_body(self):
         gi = self._g_in
@@ -571,7 +600,9 @@ class JointTrainer:
         """One step through the captured graph(s); returns the (static) report tensors."""
         self._replay_inputs(x_t, y_t, x_s, y_s, t_samples)
         self._graphs[0].replay()
-        if len(self._graphs) == 2:
-            self._reduce(self._g_mid)
-            self._graphs[1].replay()
+        if len(self._graphs) == 3:
+            self._reduce_begin()                                              # the bucket's all-reduce, on its side stream ...
+            self._graphs[1].replay()                                          # ... under GradNorm's partial backward passes
+            self._reduce_end(self._g_mid)
+            self._graphs[2].replay()
         return self._g_out

@@ -203,7 +203,7 @@ int fst_wn_fold_bwd(const int64_t* table_dev, int n_rows, const float* d_flat, c
  * d log|det W| / dW its backward needs, in ONE single-workgroup launch (in-place Gauss-Jordan with partial pivoting in double
  * precision in LDS) instead of an LU factorisation, two triangular solves and ~30 tiny launches.  out[0] = log|det W| with
  * torch.logdet's conventions (NaN for a negative determinant, -inf for a singular matrix), out[1] = sign(det);
- * inv_t [n][n] = (W^{-1})^T (NaN-filled when singular).  n <= 128. */
+ * inv_t [n][n] = (W^{-1})^T (NaN-filled when singular).  n <= 96. */
 int fst_logdet_inv(const float* W, int n, float* out /* [2] */, float* inv_t /* [n][n] */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -263,7 +263,7 @@ int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, 
  *   fst_wn_wgrad_in   dw_in[m][c][τ] = Σ_{b,t} dg[b,m,t]·a[b,c,t+(τ−1)·dil]   ([2n][n][3]),   dw_cond[m][c] = Σ dg[b,m,t]·u0[b,c,t]  ([2n][h])
  *   fst_wn_wgrad_rs   dw_rs[m][c] = Σ_{b,t} [d_a ; d_out][b,m,t]·(t·s)[b,c,t]  ([2n][n]; last layer: d_a NULL, [n][n]) — acts = t·s is
  *                     re-formed from the gate halves ts [B][2n][L] the fused forward saved
- * kind 0 = in_layer + cond_layer, 1 = res_skip.  fst_wn_wgrad_ok: 1 when the shape is served (L % 32 == 0, n < 128, h <= 32 and for
+ * kind 0 = in_layer + cond_layer, 1 = res_skip.  fst_wn_wgrad_ok: 1 when the shape is served (L % 16 == 0, n < 128, h <= 32 and for
  * kind 0 dil % 4 == 0), else the caller uses fst_conv_wgrad.  workspace: fst_wn_wgrad_workspace_floats(...) floats, written. */
 int fst_wn_wgrad_ok(int kind, int B, int L, int n, int h, int dil);
 int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, int h, int last);
@@ -326,6 +326,19 @@ int fst_gru_bwd(const float* w_hh, const float* h_all, const float* gates, const
 int fst_lstm2_fwd(const float* xproj, const float* w_hh_t, float* h2, float* save, int B, int H, int64_t numel_xproj, void* stream);
 int fst_lstm2_bwd(const float* w_hh, const float* save, const float* dh2, float* dxproj, float* dpre2, int B, int H,
                   int64_t numel_xproj, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser updates (train_and_test.py:97-106 torch.optim.RMSprop x10, Adam for CPC; stepped at :742-754) as single-pass
+ * multi-tensor launches: the *_host arguments are HOST arrays of n_tensors device pointers / element counts / learning rates;
+ * up to 64 tensors ride in one launch's kernel arguments (so a captured hipGraph replays them as they are).  Same update
+ * formulas and operation order as torch (RMSprop: centered = False, momentum = 0; Adam: the capturable branch with ONE shared
+ * device step counter, already incremented by the caller).
+ * ------------------------------------------------------------------------------------------- */
+int fst_rmsprop_multi(float* const* p_host, const float* const* g_host, float* const* v_host, const int64_t* numel_host,
+                      const float* lr_host, int n_tensors, float alpha, float eps, void* stream);
+int fst_adam_multi(float* const* p_host, const float* const* g_host, float* const* m_host, float* const* v_host,
+                   const int64_t* numel_host, int n_tensors, const float* step_dev, float lr, float beta1, float beta2, float eps,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -86,7 +86,7 @@ def test_two_rank_replicas_stay_identical():
     (_, e0, g0, n0, w0, l0), (_, e1, g1, n1, w1, l1) = out
     assert e0 == e1, "replicas diverged in eager DP steps"
     assert g0 == g1, "replicas diverged through the captured DP step"
-    assert n0 == n1 == 2                                                 # two graphs with the collectives between
+    assert n0 == n1 == 3                                                 # three graphs with the collectives between
     assert abs(w0 - 7.0) < 1e-4 and w0 == w1                             # GradNorm weights renormalised, in sync
     assert l0 != l1                                                      # ranks really saw different batches
 
@@ -267,4 +267,4 @@ def test_rccl_backend_runs_the_data_parallel_step_on_one_rank():
     procs = [ctx.Process(target=_run_worker, args=("_worker_rccl", 0, world, port, q))]
     procs[0].start()
     (_, eager_same, n_graphs, w_sum, finite), = _collect(q, world, procs)
-    assert eager_same is True and n_graphs == 2 and abs(w_sum - 7.0) < 1e-4 and finite, (eager_same, n_graphs, w_sum, finite)
+    assert eager_same is True and n_graphs == 3 and abs(w_sum - 7.0) < 1e-4 and finite, (eager_same, n_graphs, w_sum, finite)

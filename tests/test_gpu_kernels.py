@@ -580,7 +580,7 @@ def test_fused_wn_layer_data_gradient(n, h, B, L, dil, res):
                  "row sums of d_a (bias gradient)")
 
 
-@pytest.mark.parametrize("n", [1, 2, 6, 50, 128])
+@pytest.mark.parametrize("n", [1, 2, 6, 50, 96])
 def test_logdet_and_inverse_transpose_kernel(n):
     """fst_logdet_inv against fp64 numpy: log|det W|, its gradient W^{-T}, and torch.logdet's conventions for det <= 0."""
     import numpy as np
