@@ -58,7 +58,7 @@ _SIGNATURES = {
     "fst_adam_multi": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_float, c_float, c_float, c_float, c_void_p]),
     "fst_wn_wgrad_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "fst_wn_wgrad_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "fst_wn_wgrad_in": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_wn_wgrad_in": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_wgrad_rs": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_fold_fwd": (c_int, [_P, c_int, _P, _P, c_void_p]),
     "fst_wn_fold_bwd": (c_int, [_P, c_int, _P, _P, _P, c_void_p]),

@@ -771,8 +771,15 @@ __global__ __launch_bounds__(256) void logdet_inv_kernel(const float* W, int n, 
 extern "C" int fst_logdet_inv(const float* W, int n, float* out, float* inv_t, void* stream) {
   FST_REQUIRE(W && out && inv_t && n > 0 && n <= 96, "fst_logdet_inv: needs 0 < n <= 96 (one workgroup holds the matrix in LDS as doubles); n=%d", n);
   const size_t lds = (size_t)n * n * sizeof(double);
-  if (lds > 48 * 1024)
-    if (int rc = fst_allow_full_lds((const void*)logdet_inv_kernel, "fst_logdet_inv")) return rc;
+  if (lds > 48 * 1024) {
+    // (not fst_allow_full_lds: the kernel also holds a few KiB of static LDS, so "all 160 KiB dynamic" is refused)
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute((const void*)logdet_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 96 * (int)sizeof(double));
+      FST_REQUIRE(e == hipSuccess, "fst_logdet_inv: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      raised = true;
+    }
+  }
   hipLaunchKernelGGL(logdet_inv_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, W, n, out, inv_t);
   FST_LAUNCH_CHECK();
   return 0;

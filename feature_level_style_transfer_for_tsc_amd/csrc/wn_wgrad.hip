@@ -55,6 +55,7 @@ struct WwParams {
   int n_groups, ksplit, B, L, tiles_per_seq, n_tiles;
   int R;                // staged rows per stage (multiple of 16)
   int ns;               // ring slots
+  int misaligned;       // some tap shift is not a multiple of 4 samples (|shift| < 4): straddling pieces are patched in LDS
   int Kcols;            // slab row length = n_groups·xr
   float* slab;          // [ksplit][256][Kcols]
   float* slab_extra;    // [ksplit][256][2]
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
       if (k >= my_ni) break;                              // wave-uniform
       const int i = wave_s + 8 * k;
       const int t = t0 + src_t[k];
-      const bool ok = src0[k] != nullptr && t >= 0 && t < L;
+      const bool ok = src0[k] != nullptr && t > -4 && t < L;   // the piece overlaps the sequence (a straddling one is patched below)
       const char* src = ok ? reinterpret_cast<const char*>(src0[k] + ((long long)b * src_bs[k] + t0)) : zero16;
       __builtin_amdgcn_global_load_lds(WW_GLOBAL_PTR(src), WW_LDS_VOID(sl + i * 1024), 16, 0, 0);
     }
@@ -214,6 +215,32 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
       issue(tile_begin + c + depth, sl_i);
     }
     const char* const sl = ww_lds + slot * slot_bytes;
+    if (p.misaligned) {                                    // kernel argument: uniform
+      // tap shifts that are not multiples of 4 samples (dilation 1, 2): the LDS-DMA source is only 4-byte aligned (the hardware
+      // takes it), and in the first / last stage of a sequence one piece per shifted row straddles the sequence's end: its
+      // out-of-range samples are a neighbouring row's data — zero them here, behind one more barrier (2 stages in 32)
+      const int tile = tile_begin + c, bq = tile / p.tiles_per_seq, t0 = (tile - bq * p.tiles_per_seq) * WW_TT;
+      const bool at_start = t0 == 0, at_end = t0 + WW_TT >= L;
+      if (at_start || at_end) {
+        if (tid < p.xr) {
+          const int kk = g * p.xr + tid;
+          int sh = 0, c0 = kk, si = 0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (si + 1 < p.n_x && c0 >= p.x[si].rows) { c0 -= p.x[si].rows; ++si; }
+          sh = si == 0 ? p.x[0].shift : (si == 1 ? p.x[1].shift : (si == 2 ? p.x[2].shift : p.x[3].shift));
+          if (kk < p.K_main && (sh & 3) != 0) {
+            float* row = reinterpret_cast<float*>(ww_lds + slot * slot_bytes + ((WW_MROWS + tid) << 6));
+            const int gs = ww_g((tid & 31) >> 2);
+            if (at_start && sh < 0 && sh > -4)             // samples t0 + sh + j < 0 of piece 0
+              for (int j = 0; j < -sh; ++j) row[(((0 ^ gs) & 3) << 2) + j] = 0.f;
+            if (at_end && sh > 0 && sh < 4)                // samples t0 + sh + 12 + j >= L of piece 3
+              for (int j = 4 - sh; j < 4; ++j) row[(((3 ^ gs) & 3) << 2) + j] = 0.f;
+          }
+        }
+        __syncthreads();
+      }
+    }
     ww_bf16x8 ah[MT], al[MT];
     float4 araw[MT][2];
 #pragma unroll
@@ -290,30 +317,62 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   }
 }
 
-// out[m][k-row] = Σ_slabs, written in PyTorch layout: k-row kk of x segment s, channel c → w[seg.out][m·out_sm + c·out_sc + out_off]
-__global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(WwParams p) {
-  const int Kt = p.K_main < p.K ? p.K_main + p.n_extra : p.K;      // k-rows with a result
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)p.M * Kt) return;
-  const int m = (int)(idx / Kt), kk = (int)(idx - (long long)m * Kt);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (kk < p.K_main) {
-    const float* q = p.slab + (long long)m * p.Kcols + kk;
-    const long long st = (long long)WW_MROWS * p.Kcols;
-    int s = 0;
-    for (; s + 4 <= p.ksplit; s += 4) { s0 += q[s * st]; s1 += q[(s + 1) * st]; s2 += q[(s + 2) * st]; s3 += q[(s + 3) * st]; }
-    for (; s < p.ksplit; ++s) s0 += q[s * st];
-  } else {
-    const float* q = p.slab_extra + (long long)m * 2 + (kk - p.K_main);
-    for (int s = 0; s < p.ksplit; ++s) s0 += q[(long long)s * WW_MROWS * 2];
-  }
-  const float sum = (s0 + s1) + (s2 + s3);
+// out[m][k-row] = Σ_slabs, written in PyTorch layout: k-row kk of x segment s, channel c → w[seg.out][m·out_sm + c·out_sc + out_off].
+// One workgroup per (output row, 256 k-rows): thread (column quad cx, slab group sg) adds every fourth slab of its 16 bytes with
+// eight loads in flight, the four groups meet in LDS — fixed order, so the result is the same bits on every run.  (One thread
+// per element walking all slabs on its own had ~6 KB in flight per CU: 60 µs for 50 MB.)
+__device__ __forceinline__ void ww_scatter(const WwParams& p, int m, int kk, float v) {
   int si = 0, c = kk;
 #pragma unroll
   for (int j = 0; j < 3; ++j)
     if (si + 1 < p.n_x && c >= p.x[si].rows) { c -= p.x[si].rows; ++si; }
-  const WwSeg& seg = p.x[si];
-  p.w[seg.out][(long long)m * seg.out_sm + (long long)c * seg.out_sc + seg.out_off] = sum;
+  int out = p.x[0].out, off = p.x[0].out_off, sc = p.x[0].out_sc, sm = p.x[0].out_sm;
+  if (si == 1) { out = p.x[1].out; off = p.x[1].out_off; sc = p.x[1].out_sc; sm = p.x[1].out_sm; }
+  if (si == 2) { out = p.x[2].out; off = p.x[2].out_off; sc = p.x[2].out_sc; sm = p.x[2].out_sm; }
+  if (si == 3) { out = p.x[3].out; off = p.x[3].out_off; sc = p.x[3].out_sc; sm = p.x[3].out_sm; }
+  float* w = out == 0 ? p.w[0] : p.w[1];
+  w[(long long)m * sm + (long long)c * sc + off] = v;
+}
+
+__global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(WwParams p) {
+  __shared__ float4 part[4][64];
+  const int m = blockIdx.y, cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int kk0 = blockIdx.x * 256 + cx * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kk0 < p.Kcols) {
+    const long long st = (long long)WW_MROWS * p.Kcols;
+    const float* q = p.slab + (long long)m * p.Kcols + kk0;
+    int sl = sg;
+    for (; sl + 28 < p.ksplit; sl += 32) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(q + (sl + 4 * u) * st);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; sl < p.ksplit; sl += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(q + sl * st);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[sg][cx] = s;
+  __syncthreads();
+  if (sg == 0 && kk0 < p.Kcols) {
+    float4 t = part[0][cx];
+#pragma unroll
+    for (int g2 = 1; g2 < 4; ++g2) { const float4 o = part[g2][cx]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (kk0 + j < p.K_main) ww_scatter(p, m, kk0 + j, tv[j]);
+  }
+  // the leftover k-rows (VALU sums): the last column block's idle slab-group-1 threads take them
+  if (blockIdx.x == gridDim.x - 1 && sg == 1 && cx < p.n_extra && p.K_main < p.K) {
+    const float* q = p.slab_extra + (long long)m * 2 + cx;
+    float e = 0.f;
+    for (int sl = 0; sl < p.ksplit; ++sl) e += q[(long long)sl * WW_MROWS * 2];
+    ww_scatter(p, m, p.K_main + cx, e);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -346,14 +405,19 @@ static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams*
   return KT;
 }
 
+// 1: served; 2 (kind 0 only): served if 16 bytes in front of and behind `a` are readable (dilation 1-3: a tap's 16-byte pieces
+// start up to 3 samples outside a row); 0: not served
 extern "C" int fst_wn_wgrad_ok(int kind, int B, int L, int n, int h, int dil) {
   if (!(B > 0 && L > 0 && L % WW_TT == 0 && n > 0 && n < 128)) return 0;      // (16-sample stages)
-  if (kind == 0) return h > 0 && h <= 32 && dil > 0 && dil % 4 == 0 && (3 * n + h + 31) / 32 <= 18;
+  if (kind == 0) {
+    if (!(h > 0 && h <= 32 && dil > 0 && (3 * n + h + 31) / 32 <= 18)) return 0;
+    return dil % 4 == 0 ? 1 : (dil < 4 ? 2 : 0);
+  }
   return kind == 1;
 }
 
 extern "C" int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, int h, int last) {
-  if (!fst_wn_wgrad_ok(kind, B, L, n, h, 4)) return -1;
+  if (!fst_wn_wgrad_ok(kind, B, L, n, h, 4)) return -1;                        // (the workspace does not depend on the dilation)
   WwParams p;
   ww_geometry(kind, B, L, n, h, last, &p);
   return (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2);
@@ -369,19 +433,18 @@ static int ww_launch(WwParams& p, int KT, void* stream) {
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_wn_wgrad")) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
-  const int Kt = p.K_main < p.K ? p.K_main + p.n_extra : p.K;
-  const long long total = (long long)p.M * Kt;
-  hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3((unsigned)((p.Kcols + 255) / 256), (unsigned)p.M), dim3(256), 0, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0, int64_t u0_bs, float* dw_in, float* dw_cond,
-                               float* workspace, int64_t workspace_floats, int B, int L, int n, int h, int dil, int64_t numel_a,
-                               void* stream) {
+                               float* workspace, int64_t workspace_floats, int B, int L, int n, int h, int dil, int a_slack,
+                               int64_t numel_a, void* stream) {
   FST_REQUIRE(dg && a && u0 && dw_in && dw_cond && workspace, "fst_wn_wgrad_in: null operand");
-  FST_REQUIRE(fst_wn_wgrad_ok(0, B, L, n, h, dil), "fst_wn_wgrad_in: unsupported shape B=%d L=%d n=%d h=%d dil=%d (needs L %% 16 == 0, "
-              "n < 128, h <= 32, dil %% 4 == 0)", B, L, n, h, dil);
+  const int served = fst_wn_wgrad_ok(0, B, L, n, h, dil);
+  FST_REQUIRE(served == 1 || (served == 2 && a_slack), "fst_wn_wgrad_in: unsupported shape B=%d L=%d n=%d h=%d dil=%d (needs L %% 16 == 0, "
+              "n < 128, h <= 32, and dil %% 4 == 0 or — with 16 readable bytes either side of a — dil < 4)", B, L, n, h, dil);
   FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_in: B*n*L does not match the element count %lld of a", (long long)numel_a);
   FST_REQUIRE(B == 1 || u0_bs >= (int64_t)h * L, "fst_wn_wgrad_in: u0 batch stride %lld < h*L", (long long)u0_bs);
   FST_REQUIRE(u0_bs % 4 == 0 && ww_al16(dg) && ww_al16(a) && ww_al16(u0) && ww_al16(workspace), "fst_wn_wgrad_in: operands must be 16-byte aligned");
@@ -394,6 +457,7 @@ extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0,
   p.n_x = 4;
   for (int tap = 0; tap < 3; ++tap) p.x[tap] = {a, (long long)n * L, 0, n, (tap - 1) * dil, 0, tap, 3, 3 * n};
   p.x[3] = {u0, (long long)u0_bs, 0, h, 0, 1, 0, 1, h};
+  p.misaligned = dil % 4 != 0;
   p.slab = workspace;
   p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
   p.w[0] = dw_in; p.w[1] = dw_cond;

@@ -714,13 +714,26 @@ class WNSpecs:
         return [flat[self.offsets[i]: self.offsets[i + 1]].view(sh) for i, sh in enumerate(self.shapes)]
 
 
-def wn_wgrad_ok(kind: int, B: int, L: int, n: int, h: int, dil: int) -> bool:
+def wn_wgrad_ok(kind: int, B: int, L: int, n: int, h: int, dil: int, a: Optional[Tensor] = None) -> bool:
     """Whether the time-as-k weight-gradient kernels of csrc/wn_wgrad.hip serve this layer (kind 0 = in_layer + cond_layer,
-    1 = res_skip): split-bf16 arithmetic, L % 16 == 0, n < 128, h <= 32, tap shifts that are multiples of 4 samples.  Everything
-    else stays on the generic fst_conv_wgrad."""
+    1 = res_skip): split-bf16 arithmetic, L % 16 == 0, n < 128, h <= 32; tap shifts that are not multiples of 4 samples
+    (dilation 1, 2) need 16 readable bytes either side of ``a`` (``empty_with_slack``).  Everything else stays on fst_conv_wgrad."""
     if MATH != "bf16x3" or os.environ.get("FST_WN_WGRAD", "1") == "0":
         return False
-    return bool(_lib.load().fst_wn_wgrad_ok(kind, B, L, n, h, dil))
+    served = _lib.load().fst_wn_wgrad_ok(kind, B, L, n, h, dil)
+    return served == 1 or (served == 2 and a is not None and has_slack(a))
+
+
+def empty_with_slack(B: int, C: int, L: int, device) -> Tensor:
+    """A contiguous [B, C, L] fp32 tensor with 16 readable bytes in front of and behind it inside its own allocation (the
+    16-byte LDS-DMA pieces of a tap shifted by 1-3 samples start up to 3 samples outside a row: fst_wn_wgrad_in, a_slack)."""
+    buf = torch.empty(B * C * L + 8, device=device, dtype=torch.float32)
+    return buf[4: 4 + B * C * L].view(B, C, L)
+
+
+def has_slack(t: Tensor) -> bool:
+    off = t.storage_offset()
+    return t.is_contiguous() and off >= 4 and t.untyped_storage().nbytes() >= (off + t.numel() + 4) * 4
 
 
 def wn_wgrad_in(dg: Tensor, a: Tensor, u0: Tensor, dw_in: Tensor, dw_cond: Tensor, n: int, h: int, dil: int) -> None:
@@ -737,8 +750,8 @@ def wn_wgrad_in(dg: Tensor, a: Tensor, u0: Tensor, dw_in: Tensor, dw_cond: Tenso
     ws_n = lib.fst_wn_wgrad_workspace_floats(0, B, L, n, h, 0)
     ws = torch.empty(ws_n, device=dg.device, dtype=torch.float32)
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
-    check(lib.fst_wn_wgrad_in(ptr(dg), ptr(a), ptr(u0), u0_bs, ptr(dw_in), ptr(dw_cond), ptr(ws), ws_n, B, L, n, h, dil, numel,
-                              stream_ptr()), "fst_wn_wgrad_in")
+    check(lib.fst_wn_wgrad_in(ptr(dg), ptr(a), ptr(u0), u0_bs, ptr(dw_in), ptr(dw_cond), ptr(ws), ws_n, B, L, n, h, dil,
+                              int(has_slack(a)), numel, stream_ptr()), "fst_wn_wgrad_in")
     if t0 is not None:
         KERNEL_TIMER.end("wn_wgrad_kernel<2, 3>", t0, 2.0 * B * L * 2 * n * (3 * n + h), 4.0 * B * L * (2 * n + n + h))
 
@@ -1031,7 +1044,9 @@ def _wn_forward(specs: WNSpecs, u0: Tensor, flat: Tensor):
     rs_w, rs_b = weights[6 + 2 * nl: 6 + 3 * nl], weights[6 + 3 * nl: 6 + 4 * nl]
     B, _, L = u0.shape
     h, n = S.h, S.n
-    a = S.start.forward(u0, None, start_w, None, start_b)
+    # the layer inputs are allocated with 16 bytes of slack either side: the time-as-k weight-gradient kernel reads the taps of
+    # dilation 1 and 2 through 16-byte pieces that start up to 3 samples outside a row
+    a = S.start.forward(u0, None, start_w, None, start_b, y=empty_with_slack(B, n, L, u0.device))
     a_list, ts_list, acts_list = [a], [], []
     fused = wn_fused_ok(n, h, L, a, u0, kernel=S.kernel)
     if fused:
@@ -1042,7 +1057,7 @@ def _wn_forward(specs: WNSpecs, u0: Tensor, flat: Tensor):
             last = i == nl - 1
             img = wn_pack_layer(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], in_b[i], cb[i], rs_w[i], rs_b[i], n, h, last)
             ts = torch.empty(B, 2 * n, L, device=u0.device, dtype=torch.float32)
-            a_next = None if last else torch.empty_like(a)
+            a_next = None if last else empty_with_slack(B, n, L, u0.device)
             # acts = t·s is not written: the res_skip weight gradient re-forms it from the saved halves while staging
             wn_layer_fwd(a, u0, img, ts, None, a_next, out, i == 0, last, n, h, 2 ** i)
             ts_list.append(ts)
@@ -1158,7 +1173,7 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
                                    stream_ptr()), "fst_gate_bwd")
         if need_w:
             # in_layer weights and the layer's rows of the stacked cond_layer weights, unpacked in place
-            if fused and wn_wgrad_ok(0, B, L, n, h, 2 ** i):
+            if fused and wn_wgrad_ok(0, B, L, n, h, 2 ** i, a_list[i]):
                 wn_wgrad_in(dg, a_list[i], u0, g_in_w[i], g_cond_w[2 * n * i: 2 * n * (i + 1)], n, h, 2 ** i)
             else:
                 S.ins[i].grad_w(a_list[i], u0, dg, out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])

@@ -202,6 +202,7 @@ def test_joint_step_gradients_at_batch_32(arithmetic):
 
 
 @pytest.mark.parametrize("n,h,Bq,L,dil", [(120, 25, 256, 512, 4), (120, 25, 256, 512, 128), (120, 25, 64, 1024, 16),
+                                          (120, 25, 256, 512, 1), (120, 25, 256, 512, 2), (33, 31, 3, 48, 1), (8, 3, 2, 16, 2), (16, 5, 2, 64, 3),
                                           (8, 3, 3, 64, 4), (33, 31, 2, 96, 8), (127, 32, 2, 128, 4), (16, 16, 5, 32, 8),
                                           (120, 25, 1, 32, 4)])      # one tile in all: most workgroups have nothing to do
 def test_time_as_k_weight_gradient_kernels(n, h, Bq, L, dil):
@@ -209,9 +210,14 @@ def test_time_as_k_weight_gradient_kernels(n, h, Bq, L, dil):
     in_layer + cond_layer (three dilated taps, the 385th k-row on the VALU) and res_skip with acts = t·s re-formed from the saved
     halves (both row counts); twice, bit for bit the same (no atomics)."""
     g = torch.Generator(device=DEV).manual_seed(n * 7 + L + dil)
-    assert ops.wn_wgrad_ok(0, Bq, L, n, h, dil) and ops.wn_wgrad_ok(1, Bq, L, n, h, dil)
-    assert not ops.wn_wgrad_ok(0, Bq, L, n, h, 2) and not ops.wn_wgrad_ok(0, Bq, L + 4, n, h, dil)
-    a, dgd = _rnd(g, Bq, n, L), _rnd(g, Bq, 2 * n, L)
+    # the layer input sits between two poisoned guard bands: a tap shifted by 1-3 samples reads up to 3 floats outside it
+    a = ops.empty_with_slack(Bq, n, L, DEV)
+    a.untyped_storage().copy_(torch.full((Bq * n * L + 8,), float("nan")).untyped_storage())
+    a.copy_(_rnd(g, Bq, n, L))
+    dgd = _rnd(g, Bq, 2 * n, L)
+    assert ops.wn_wgrad_ok(0, Bq, L, n, h, dil, a) and ops.wn_wgrad_ok(1, Bq, L, n, h, dil)
+    assert ops.wn_wgrad_ok(0, Bq, L, n, h, 2, a) and not ops.wn_wgrad_ok(0, Bq, L, n, h, 2, a.clone())   # no slack: not served
+    assert not ops.wn_wgrad_ok(0, Bq, L, n, h, 6, a) and not ops.wn_wgrad_ok(0, Bq, L + 4, n, h, dil, a)
     u0 = _rnd(g, Bq, 2 * h, L)[:, :h]                                   # a channel-slice view, as the flow passes it
     dw_in, dw_cond = torch.full((2 * n, n, 3), 7.0, device=DEV), torch.full((2 * n, h, 1), 7.0, device=DEV)
     ops.wn_wgrad_in(dgd, a, u0, dw_in, dw_cond, n, h, dil)
