@@ -10,18 +10,18 @@
 // conv_wgrad_kernel it replaces for these shapes (99 µs, MFMA-busy 0.24, 706 MB through L2 → LDS for 202 MB of operands):
 //   * one 8-wave workgroup per CU owns ALL 2n output rows × 192 k-rows (6 blocks; in_layer: two such groups, so dy passes the
 //     L2 → LDS path twice instead of four times) for a contiguous range of 32-sample time tiles;
-//   * operands reach LDS by LDS-DMA as raw fp32 rows of 16 samples (64 B = one MFMA k-step) through a ring of 4-5 slots with
-//     3-4 stages in flight behind counted vmcnt waits, ONE barrier per stage (a two-slot ring of 32-sample tiles, which issues
-//     a tile only when its predecessor has landed, ran at a third of this rate: no overlap of one tile's latency with the
-//     next one's transfer); a row's four 16-byte pieces are XOR-swizzled by a function of the row, so the fragment reads
-//     (two ds_read_b128 per fragment) are bank-conflict-free although rows are 16 banks apart;
+//   * operands reach LDS by LDS-DMA as raw fp32 rows of 32 samples (128 B: whole cache lines — 64-byte rows fetched every line
+//     twice, 152 µs) through two rings behind counted vmcnt waits, ONE barrier per stage: three slots for the dy rows (two
+//     stages ahead), two for the k-rows (all that fits in 160 KiB), so the wait of a stage exposes the latency and transfer of
+//     the k-rows only; a row's eight 16-byte pieces are XOR-swizzled by (row & 7) and every second octet of rows swaps row
+//     parity, so the fragment reads (two ds_read_b128 per fragment) are bank-conflict-free although rows are 128 B apart;
 //   * each wave multiplies a 2 × 3 (res_skip: 2 × 2) tile of 32×32 blocks: five raw fragments are split into bf16 hi/lo in
 //     registers per k-step for 18 triple-MFMAs (hi·hi + hi·lo + lo·hi, fp32 accumulate);
 //   * a k-row count one past a multiple of 32 (3·120 + 25 = 385) does not cost a thirteenth block: the leftover row is
 //     accumulated on the VALU from the dy fragments the wave holds anyway;
 //   * every workgroup stores its partial D tile into its own slab (plain stores, two full 128-B segments per instruction);
 //     wn_wgrad_reduce_kernel adds the slabs in a fixed order and writes PyTorch layout: deterministic, no atomics.
-// Served: L % 16 == 0, n < 128 (M ≤ 256), h ≤ 32, tap shifts that are multiples of 4 samples (dil % 4 == 0), 16-byte aligned
+// Served: L % 32 == 0, n < 128 (M ≤ 256), h ≤ 32, tap shifts that are multiples of 4 samples (dil % 4 == 0), 16-byte aligned
 // tensors; everything else stays on conv_wgrad_kernel (fst_wn_wgrad_ok tells).
 #include "fst_common.h"
 
@@ -32,9 +32,11 @@ typedef unsigned ww_u32x4 __attribute__((ext_vector_type(4)));
 #define WW_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define WW_LDS_VOID(p) ((__attribute__((address_space(3))) void*)(p))
 
-#define WW_TT 16          // time samples per stage = one MFMA k-step = one 64-byte LDS row
+#define WW_TT 32          // time samples per stage = two MFMA k-steps = one 128-byte LDS row (a full cache line per row)
 #define WW_MROWS 256      // staged dy rows (8 blocks of 32)
-#define WW_MAX_NI 5       // LDS-DMA instructions (16 rows each) per wave and stage
+#define WW_ND 3           // ring slots of the dy rows
+#define WW_NX 2           // ring slots of the k-rows
+#define WW_MAX_NX 5       // LDS-DMA instructions (8 rows each) per wave and stage for the k-rows
 
 __device__ __attribute__((aligned(16))) float ww_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -53,8 +55,7 @@ struct WwParams {
   int xr;               // staged k-rows per group = 32·2·KT
   int mul;              // 1: every k-row is staged twice (row and partner) and multiplied when its fragment is read
   int n_groups, ksplit, B, L, tiles_per_seq, n_tiles;
-  int R;                // staged rows per stage (multiple of 16)
-  int ns;               // ring slots
+  int RX;               // staged rows of a k-row slot: xr·(1 + mul) (+ 8 for the leftover rows), a multiple of 8
   int misaligned;       // some tap shift is not a multiple of 4 samples (|shift| < 4): straddling pieces are patched in LDS
   int Kcols;            // slab row length = n_groups·xr
   float* slab;          // [ksplit][256][Kcols]
@@ -84,19 +85,18 @@ template <int N>
 __device__ __forceinline__ void ww_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void ww_wait_sw(int n) {      // counted wait for a wave-uniform run-time count
-  if (n >= N) { ww_wait_vmcnt<N>(); return; }
-  if constexpr (N > 0) ww_wait_sw<N - 1>(n);
-}
 
-// A staged row is 16 samples = four 16-byte pieces (64 B); row r sits at r·64 and its piece q at slot q ^ ww_g((r & 31) >> 2):
-// the sixteen lanes a ds_read_b128 services together (rows {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of a block) then
-// cover all 64 banks (checked exhaustively on the host side of the tests' development; rows alone are 16 banks apart).
-__device__ __forceinline__ int ww_g(int x) { return x < 4 ? (x >> 1) : 2 + (x & 1); }
+// A staged row is 32 samples = eight 16-byte pieces (128 B, one cache line of the tensor row).  Logical row r of a region sits at
+// LDS row r ^ ((r >> 3) & 1) (odd octets swap the parity of their rows) and its piece q at slot (q ^ r) & 7: the sixteen lanes a
+// ds_read_b128 services together (rows {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of a block) then cover all 64 banks although
+// rows are a multiple of 128 B apart.  An LDS-DMA instruction fills 8 LDS rows (1 KiB, lane-linear): lane → LDS row 8i + (lane >> 3),
+// piece slot lane & 7.
+__device__ __forceinline__ int ww_dma_row(int i, int lane) { return 8 * i + ((lane >> 3) ^ (i & 1)); }
 
-// FULL: every output-row block and every k-row block of every group is live (M = 256-ish, K_main a multiple of the group size):
-// no block tests in the inner loop.
+// which tensor row / piece a lane of a k-row DMA instruction fetches → (address for batch 0, t0 = 0; batch stride; first sample)
+struct WwSrc { const float* p; int bs, t; };
+
+// FULL: every output-row block and every k-row block of every group is live: no block tests in the inner loop.
 template <int MT, int KT, bool FULL>
 __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   extern __shared__ __attribute__((aligned(16))) char ww_lds[];
@@ -104,73 +104,88 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_s >> 1, wk = wave_s & 1;          // 4 (output-row pairs) × 2 (k-row halves of the group)
   const int g = blockIdx.y, L = p.L;
-  const int slot_bytes = p.R * 64;
+  const int dslot_bytes = WW_MROWS * 128, xslot_bytes = p.RX * 128;
+  char* const xring = ww_lds + WW_ND * dslot_bytes;
   const char* const zero16 = reinterpret_cast<const char*>(ww_zero16);
 
-  // ---- per (LDS-DMA instruction of this wave, lane): which 16 bytes of which tensor row it fetches.  Instruction i fills the
-  // LDS rows 16i..16i+15 (1 KiB, lane-linear): lane → row 16i + (lane >> 2), piece slot lane & 3.  Staged rows: [0, 256) dy
-  // rows, [256, 256 + xr) this group's k-rows, [.., + xr) their partners (product operand), then 16 rows for the leftover
-  // k-rows (group 0 only).
-  const int NI = p.R >> 4;
-  const int my_ni = (NI - wave_s + 7) >> 3;               // instructions i = wave, wave + 8, ...  (wave-uniform count)
-  const float* src0[WW_MAX_NI];                           // address of the piece in batch element 0 at t0 = 0 (null: zero fill)
-  int src_bs[WW_MAX_NI], src_t[WW_MAX_NI];                // batch stride (floats); first sample of the piece relative to t0
+  // ---- dy rows: 32 LDS-DMA instructions per stage, 4 per wave (i = wave + 8k)
+  WwSrc dsrc[4];
 #pragma unroll
-  for (int k = 0; k < WW_MAX_NI; ++k) {
-    src0[k] = nullptr; src_bs[k] = 0; src_t[k] = 0;
+  for (int k = 0; k < 4; ++k) {
     const int i = wave_s + 8 * k;
-    if (k >= my_ni) continue;
-    const int r = 16 * i + (lane >> 2);
-    const int q = (lane ^ ww_g((r & 31) >> 2)) & 3;
-    int which = -1, c = 0;                                 // 0, 1: dy segments; 2..5: x segments
-    bool partner = false;
-    if (r < WW_MROWS) {
-      if (r < p.M) {
-        if (p.n_dy > 1 && r >= p.dy[0].rows) { which = 1; c = r - p.dy[0].rows; } else { which = 0; c = r; }
-      }
-    } else {
-      const int rr = r - WW_MROWS;
-      int kk = -1;
-      if (rr < p.xr) kk = g * p.xr + rr;
-      else if (p.mul && rr < 2 * p.xr) { kk = g * p.xr + rr - p.xr; partner = true; }
-      else {
-        const int e = rr - p.xr * (1 + p.mul);            // leftover rows: the k-rows K_main .. K-1, staged by group 0
-        if (g == 0 && e < p.n_extra) kk = p.K_main + e;
-      }
-      if (kk >= 0 && kk < p.K && (kk < p.K_main || rr >= p.xr * (1 + p.mul))) {
-        int s = 0, c0 = kk;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          if (s + 1 < p.n_x && c0 >= p.x[s].rows) { c0 -= p.x[s].rows; ++s; }
-        which = 2 + s; c = c0;
+    const int r = ww_dma_row(i, lane), q = (lane ^ r) & 7;
+    dsrc[k].p = nullptr; dsrc[k].bs = 0; dsrc[k].t = 4 * q;
+    if (r < p.M) {
+      if (p.n_dy > 1 && r >= p.dy[0].rows) {
+        dsrc[k].p = p.dy[1].ptr + ((long long)(r - p.dy[0].rows) * L + 4 * q); dsrc[k].bs = (int)p.dy[1].bs;
+      } else {
+        dsrc[k].p = p.dy[0].ptr + ((long long)r * L + 4 * q); dsrc[k].bs = (int)p.dy[0].bs;
       }
     }
-    // the segment's fields by a chain of compares (kernel arguments are read with scalar loads; no pointer into the argument block)
-    const float* sp = nullptr;
-    long long sbs = 0, smo = 0;
-    int ssh = 0;
-#define WW_PICK(W, SEG) if (which == (W)) { sp = SEG.ptr; sbs = SEG.bs; smo = SEG.mul_off; ssh = SEG.shift; }
-    WW_PICK(0, p.dy[0]) WW_PICK(1, p.dy[1]) WW_PICK(2, p.x[0]) WW_PICK(3, p.x[1]) WW_PICK(4, p.x[2]) WW_PICK(5, p.x[3])
-#undef WW_PICK
-    if (which >= 0) {
-      src0[k] = sp + ((long long)c * L + ssh + 4 * q) + (partner ? smo : 0);
-      src_bs[k] = (int)sbs;
-      src_t[k] = ssh + 4 * q;
+  }
+  // ---- k-rows of this group: [0, xr) the rows, [xr, 2·xr) their partners (product operand), then 8 rows for the leftover
+  // k-rows (group 0 only); RX/8 instructions per stage
+  const int NXI = p.RX >> 3;
+  const int my_nx = (NXI - wave_s + 7) >> 3;
+  WwSrc xsrc[WW_MAX_NX];
+#pragma unroll
+  for (int k = 0; k < WW_MAX_NX; ++k) {
+    xsrc[k].p = nullptr; xsrc[k].bs = 0; xsrc[k].t = 0;
+    const int i = wave_s + 8 * k;
+    if (k >= my_nx) continue;
+    const int rr = ww_dma_row(i, lane), q = (lane ^ rr) & 7;
+    int kk = -1;
+    bool partner = false;
+    if (rr < p.xr) kk = g * p.xr + rr;
+    else if (p.mul && rr < 2 * p.xr) { kk = g * p.xr + rr - p.xr; partner = true; }
+    else {
+      const int e = rr - p.xr * (1 + p.mul);              // leftover rows: the k-rows K_main .. K-1, staged by group 0
+      if (g == 0 && e < p.n_extra) kk = p.K_main + e;
+    }
+    if (kk >= 0 && kk < p.K && (kk < p.K_main || rr >= p.xr * (1 + p.mul))) {
+      int si = 0, c0 = kk;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (si + 1 < p.n_x && c0 >= p.x[si].rows) { c0 -= p.x[si].rows; ++si; }
+      // the segment's fields by a chain of compares (kernel arguments are read with scalar loads; no pointer into the argument block)
+      const float* sp = p.x[0].ptr;
+      long long sbs = p.x[0].bs, smo = p.x[0].mul_off;
+      int ssh = p.x[0].shift;
+      if (si == 1) { sp = p.x[1].ptr; sbs = p.x[1].bs; smo = p.x[1].mul_off; ssh = p.x[1].shift; }
+      if (si == 2) { sp = p.x[2].ptr; sbs = p.x[2].bs; smo = p.x[2].mul_off; ssh = p.x[2].shift; }
+      if (si == 3) { sp = p.x[3].ptr; sbs = p.x[3].bs; smo = p.x[3].mul_off; ssh = p.x[3].shift; }
+      xsrc[k].p = sp + ((long long)c0 * L + ssh + 4 * q) + (partner ? smo : 0);
+      xsrc[k].bs = (int)sbs;
+      xsrc[k].t = ssh + 4 * q;
     }
   }
 
-  auto issue = [&](int tile, int slot) {
-    const int b = tile / p.tiles_per_seq;
-    const int t0 = (tile - b * p.tiles_per_seq) * WW_TT;
-    char* const sl = ww_lds + slot * slot_bytes;
+  auto tile_bt = [&](int tile, int& b, int& t0) {
+    b = tile / p.tiles_per_seq;
+    t0 = (tile - b * p.tiles_per_seq) * WW_TT;
+  };
+  auto issue_dy = [&](int tile, int slot) {
+    int b, t0;
+    tile_bt(tile, b, t0);
+    char* const sl = ww_lds + slot * dslot_bytes;
 #pragma unroll
-    for (int k = 0; k < WW_MAX_NI; ++k) {
-      if (k >= my_ni) break;                              // wave-uniform
-      const int i = wave_s + 8 * k;
-      const int t = t0 + src_t[k];
-      const bool ok = src0[k] != nullptr && t > -4 && t < L;   // the piece overlaps the sequence (a straddling one is patched below)
-      const char* src = ok ? reinterpret_cast<const char*>(src0[k] + ((long long)b * src_bs[k] + t0)) : zero16;
-      __builtin_amdgcn_global_load_lds(WW_GLOBAL_PTR(src), WW_LDS_VOID(sl + i * 1024), 16, 0, 0);
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = dsrc[k].p != nullptr && t0 + dsrc[k].t < L;
+      const char* src = ok ? reinterpret_cast<const char*>(dsrc[k].p + ((long long)b * dsrc[k].bs + t0)) : zero16;
+      __builtin_amdgcn_global_load_lds(WW_GLOBAL_PTR(src), WW_LDS_VOID(sl + (wave_s + 8 * k) * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_x = [&](int tile, int slot) {
+    int b, t0;
+    tile_bt(tile, b, t0);
+    char* const sl = xring + slot * xslot_bytes;
+#pragma unroll
+    for (int k = 0; k < WW_MAX_NX; ++k) {
+      if (k >= my_nx) break;                              // wave-uniform
+      const int t = t0 + xsrc[k].t;
+      const bool ok = xsrc[k].p != nullptr && t > -4 && t < L;   // the piece overlaps the sequence (a straddling one is patched below)
+      const char* src = ok ? reinterpret_cast<const char*>(xsrc[k].p + ((long long)b * xsrc[k].bs + t0)) : zero16;
+      __builtin_amdgcn_global_load_lds(WW_GLOBAL_PTR(src), WW_LDS_VOID(sl + (wave_s + 8 * k) * 1024), 16, 0, 0);
     }
   };
 
@@ -191,103 +206,111 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   const int k_blocks_here = min(2 * KT, ((p.K_main + 31) >> 5) - g * 2 * KT);   // live k-row blocks of this group
   const bool do_extra = g == 0 && wk == 0 && p.n_extra > 0;
 
-  // fragment addressing: row block·32 + l31, pieces 2·half and 2·half + 1 (the 8 samples of this lane half)
-  const int gsw = ww_g(l31 >> 2);
-  const int row_l = l31 << 6;
-  const int pc0 = (((2 * half) ^ gsw) & 3) << 4, pc1 = (((2 * half + 1) ^ gsw) & 3) << 4;
-  const int a_base = ((wm * MT * 32) << 6) + row_l;
-  const int x_base = ((WW_MROWS + wk * KT * 32) << 6) + row_l, xp_base = x_base + (p.xr << 6);
-  const int e_base = (WW_MROWS + p.xr * (1 + p.mul)) << 6;      // rows e < 16 of this octet: g(e >> 2) = e >> 3 for e < 8: 0
+  // fragment addressing: row block·32 + l31 (LDS row l31 ^ ((l31 >> 3) & 1) of the block), pieces 4·ks + 2·half and the next
+  const int row_l = (l31 ^ ((l31 >> 3) & 1)) << 7;
+  const int sw = l31 & 7;
+  int pc[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    pc[ks][0] = (((4 * ks + 2 * half) ^ sw) & 7) << 4;
+    pc[ks][1] = (((4 * ks + 2 * half + 1) ^ sw) & 7) << 4;
+  }
+  const int a_off = ((wm * MT * 32) << 7) + row_l;
+  const int x_off = ((wk * KT * 32) << 7) + row_l, xp_off = x_off + (p.xr << 7);
+  const int e_off = (p.xr * (1 + p.mul)) << 7;           // the leftover rows' octet: LDS row = e, piece slot = (q ^ e) & 7
 
-  // ring: `depth` stages in flight; one barrier per stage
-  const int ns = p.ns, depth = ns - 1;
+  // Two rings, one barrier per stage: the dy rows run two stages ahead (three slots), the k-rows one (two slots — all that fits
+  // beside them in 160 KiB).  Issue order per stage c: x(c+1), then dy(c+2); so the wait for stage c leaves exactly the pieces of
+  // dy(c+1) in flight, and what is exposed per stage is the latency plus the transfer of the k-rows alone.
   const int n_st = tile_end - tile_begin;
-  for (int d = 0; d < depth && d < n_st; ++d) issue(tile_begin + d, d);
-  int slot = 0;
+  if (n_st > 0) { issue_dy(tile_begin, 0); issue_x(tile_begin, 0); }
+  if (n_st > 1) issue_dy(tile_begin + 1, 1);
+  int dslot = 0, xslot = 0;
   for (int c = 0; c < n_st; ++c) {
-    // stages still allowed in flight behind stage c: those already issued, i.e. min(depth - 1, n_st - 1 - c)
-    const int newer = min(depth - 1, n_st - 1 - c);
-    ww_wait_sw<16>(newer * my_ni);
+    if (c + 1 < n_st) ww_wait_vmcnt<4>(); else ww_wait_vmcnt<0>();   // (a wave issues 4 dy pieces per stage)
     __builtin_amdgcn_s_barrier();                          // everyone's pieces of stage c have landed; stage c - 1 has been read by all
-    if (c + depth < n_st) {
-      int sl_i = slot + depth;
-      if (sl_i >= ns) sl_i -= ns;
-      issue(tile_begin + c + depth, sl_i);
-    }
-    const char* const sl = ww_lds + slot * slot_bytes;
+    if (c + 1 < n_st) issue_x(tile_begin + c + 1, xslot ^ 1);
+    if (c + 2 < n_st) issue_dy(tile_begin + c + 2, dslot >= 1 ? dslot - 1 : 2);
+    const char* const dsl = ww_lds + dslot * dslot_bytes;
+    const char* const xsl = xring + xslot * xslot_bytes;
     if (p.misaligned) {                                    // kernel argument: uniform
-      // tap shifts that are not multiples of 4 samples (dilation 1, 2): the LDS-DMA source is only 4-byte aligned (the hardware
+      // tap shifts that are not multiples of 4 samples (dilation 1-3): the LDS-DMA source is only 4-byte aligned (the hardware
       // takes it), and in the first / last stage of a sequence one piece per shifted row straddles the sequence's end: its
-      // out-of-range samples are a neighbouring row's data — zero them here, behind one more barrier (2 stages in 32)
-      const int tile = tile_begin + c, bq = tile / p.tiles_per_seq, t0 = (tile - bq * p.tiles_per_seq) * WW_TT;
+      // out-of-range samples are a neighbouring row's data — zero them here, behind one more barrier (2 stages in L/32)
+      int bq, t0;
+      tile_bt(tile_begin + c, bq, t0);
       const bool at_start = t0 == 0, at_end = t0 + WW_TT >= L;
       if (at_start || at_end) {
         if (tid < p.xr) {
           const int kk = g * p.xr + tid;
-          int sh = 0, c0 = kk, si = 0;
+          int c0 = kk, si = 0;
 #pragma unroll
           for (int j = 0; j < 3; ++j)
             if (si + 1 < p.n_x && c0 >= p.x[si].rows) { c0 -= p.x[si].rows; ++si; }
-          sh = si == 0 ? p.x[0].shift : (si == 1 ? p.x[1].shift : (si == 2 ? p.x[2].shift : p.x[3].shift));
+          const int sh = si == 0 ? p.x[0].shift : (si == 1 ? p.x[1].shift : (si == 2 ? p.x[2].shift : p.x[3].shift));
           if (kk < p.K_main && (sh & 3) != 0) {
-            float* row = reinterpret_cast<float*>(ww_lds + slot * slot_bytes + ((WW_MROWS + tid) << 6));
-            const int gs = ww_g((tid & 31) >> 2);
+            char* rowp = xring + xslot * xslot_bytes + ((tid ^ ((tid >> 3) & 1)) << 7);
             if (at_start && sh < 0 && sh > -4)             // samples t0 + sh + j < 0 of piece 0
-              for (int j = 0; j < -sh; ++j) row[(((0 ^ gs) & 3) << 2) + j] = 0.f;
-            if (at_end && sh > 0 && sh < 4)                // samples t0 + sh + 12 + j >= L of piece 3
-              for (int j = 4 - sh; j < 4; ++j) row[(((3 ^ gs) & 3) << 2) + j] = 0.f;
+              for (int j = 0; j < -sh; ++j) reinterpret_cast<float*>(rowp + (((0 ^ tid) & 7) << 4))[j] = 0.f;
+            if (at_end && sh > 0 && sh < 4)                // samples t0 + sh + 28 + j >= L of piece 7
+              for (int j = 4 - sh; j < 4; ++j) reinterpret_cast<float*>(rowp + (((7 ^ tid) & 7) << 4))[j] = 0.f;
           }
         }
-        __syncthreads();
-      }
-    }
-    ww_bf16x8 ah[MT], al[MT];
-    float4 araw[MT][2];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const char* ap = sl + a_base + ((i * 32) << 6);
-      araw[i][0] = *reinterpret_cast<const float4*>(ap + pc0);
-      araw[i][1] = *reinterpret_cast<const float4*>(ap + pc1);
-      ww_split8(araw[i][0], araw[i][1], ah[i], al[i]);
-    }
-    if (do_extra) {
-      // leftover k-rows on the VALU: every lane of a half reads the same 8 samples of the row (a broadcast), lane = output row
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (e >= p.n_extra) break;
-        const char* ep = sl + e_base + (e << 6);
-        const float4 x0 = *reinterpret_cast<const float4*>(ep + ((2 * half) << 4));
-        const float4 x1 = *reinterpret_cast<const float4*>(ep + ((2 * half + 1) << 4));
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-          ev[i][e] += (araw[i][0].x * x0.x + araw[i][0].y * x0.y) + (araw[i][0].z * x0.z + araw[i][0].w * x0.w) +
-                      (araw[i][1].x * x1.x + araw[i][1].y * x1.y) + (araw[i][1].z * x1.z + araw[i][1].w * x1.w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zeroing stores; NOT __syncthreads(): its fence would drain the ring
+        __builtin_amdgcn_s_barrier();
       }
     }
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      if (!FULL && wk * KT + j >= k_blocks_here) break;    // wave-uniform: blocks beyond K hold zeros
-      const char* bp = sl + x_base + ((j * 32) << 6);
-      float4 b0 = *reinterpret_cast<const float4*>(bp + pc0);
-      float4 b1 = *reinterpret_cast<const float4*>(bp + pc1);
-      if (p.mul) {                                         // kernel argument: uniform
-        const char* qp = sl + xp_base + ((j * 32) << 6);
-        const float4 c0 = *reinterpret_cast<const float4*>(qp + pc0);
-        const float4 c1 = *reinterpret_cast<const float4*>(qp + pc1);
-        b0.x *= c0.x; b0.y *= c0.y; b0.z *= c0.z; b0.w *= c0.w;
-        b1.x *= c1.x; b1.y *= c1.y; b1.z *= c1.z; b1.w *= c1.w;
-      }
-      ww_bf16x8 bh, bl;
-      ww_split8(b0, b1, bh, bl);
+    for (int ks = 0; ks < 2; ++ks) {
+      ww_bf16x8 ah[MT], al[MT];
+      float4 araw[MT][2];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        if (!FULL && wm * MT + i >= m_blocks) break;       // wave-uniform
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        const char* ap = dsl + a_off + ((i * 32) << 7);
+        araw[i][0] = *reinterpret_cast<const float4*>(ap + pc[ks][0]);
+        araw[i][1] = *reinterpret_cast<const float4*>(ap + pc[ks][1]);
+        ww_split8(araw[i][0], araw[i][1], ah[i], al[i]);
+      }
+      if (do_extra) {
+        // leftover k-rows on the VALU: every lane of a half reads the same 8 samples of the row (a broadcast), lane = output row
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (e >= p.n_extra) break;
+          const char* ep = xsl + e_off + (e << 7);
+          const float4 x0 = *reinterpret_cast<const float4*>(ep + ((((4 * ks + 2 * half) ^ e) & 7) << 4));
+          const float4 x1 = *reinterpret_cast<const float4*>(ep + ((((4 * ks + 2 * half + 1) ^ e) & 7) << 4));
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            ev[i][e] += (araw[i][0].x * x0.x + araw[i][0].y * x0.y) + (araw[i][0].z * x0.z + araw[i][0].w * x0.w) +
+                        (araw[i][1].x * x1.x + araw[i][1].y * x1.y) + (araw[i][1].z * x1.z + araw[i][1].w * x1.w);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        if (!FULL && wk * KT + j >= k_blocks_here) break;  // wave-uniform: blocks beyond K hold zeros
+        const char* bp = xsl + x_off + ((j * 32) << 7);
+        float4 b0 = *reinterpret_cast<const float4*>(bp + pc[ks][0]);
+        float4 b1 = *reinterpret_cast<const float4*>(bp + pc[ks][1]);
+        if (p.mul) {                                       // kernel argument: uniform
+          const char* qp = xsl + xp_off + ((j * 32) << 7);
+          const float4 c0 = *reinterpret_cast<const float4*>(qp + pc[ks][0]);
+          const float4 c1 = *reinterpret_cast<const float4*>(qp + pc[ks][1]);
+          b0.x *= c0.x; b0.y *= c0.y; b0.z *= c0.z; b0.w *= c0.w;
+          b1.x *= c1.x; b1.y *= c1.y; b1.z *= c1.z; b1.w *= c1.w;
+        }
+        ww_bf16x8 bh, bl;
+        ww_split8(b0, b1, bh, bl);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (!FULL && wm * MT + i >= m_blocks) break;     // wave-uniform
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        }
       }
     }
-    slot = slot + 1 == ns ? 0 : slot + 1;
+    dslot = dslot == WW_ND - 1 ? 0 : dslot + 1;
+    xslot ^= 1;
   }
 
   // ---- partial D tile → this workgroup's slab: register r of a tile = output row (r&3) + 8(r>>2) + 4·half, lane & 31 = k-row:
@@ -390,9 +413,7 @@ static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams*
   const int kb = (p->K_main + 31) / 32;
   p->n_groups = (kb + 2 * KT - 1) / (2 * KT);
   p->mul = kind == 1;
-  p->R = WW_MROWS + p->xr * (1 + p->mul) + (p->n_extra ? 16 : 0);
-  p->ns = (int)((160 * 1024) / ((size_t)p->R * 64));
-  if (p->ns > 5) p->ns = 5;
+  p->RX = p->xr * (1 + p->mul) + (p->n_extra ? 8 : 0);
   p->Kcols = p->n_groups * p->xr;
   p->B = B; p->L = L;
   p->tiles_per_seq = L / WW_TT;
@@ -408,7 +429,7 @@ static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams*
 // 1: served; 2 (kind 0 only): served if 16 bytes in front of and behind `a` are readable (dilation 1-3: a tap's 16-byte pieces
 // start up to 3 samples outside a row); 0: not served
 extern "C" int fst_wn_wgrad_ok(int kind, int B, int L, int n, int h, int dil) {
-  if (!(B > 0 && L > 0 && L % WW_TT == 0 && n > 0 && n < 128)) return 0;      // (16-sample stages)
+  if (!(B > 0 && L > 0 && L % WW_TT == 0 && n > 0 && n < 128)) return 0;      // (32-sample stages)
   if (kind == 0) {
     if (!(h > 0 && h <= 32 && dil > 0 && (3 * n + h + 31) / 32 <= 18)) return 0;
     return dil % 4 == 0 ? 1 : (dil < 4 ? 2 : 0);
@@ -424,9 +445,8 @@ extern "C" int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, 
 }
 
 static int ww_launch(WwParams& p, int KT, void* stream) {
-  const size_t lds = (size_t)p.ns * p.R * 64;
-  FST_REQUIRE(p.ns >= 2 && lds <= 160 * 1024 && (p.R >> 4) <= 8 * WW_MAX_NI && ((p.R >> 4) + 7) / 8 * (p.ns - 2) <= 16,
-              "fst_wn_wgrad: %d staged rows per stage do not fit (ring of %d slots, LDS %zu B)", p.R, p.ns, lds);
+  const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + (size_t)WW_NX * p.RX * 128;
+  FST_REQUIRE(lds <= 160 * 1024 && (p.RX >> 3) <= 8 * WW_MAX_NX, "fst_wn_wgrad: %d staged k-rows per stage do not fit (LDS %zu B)", p.RX, lds);
   const bool full = (p.M + 31) / 32 == 8 && ((p.K_main + 31) / 32) % (2 * KT) == 0;
   void (*fn)(WwParams) = KT == 3 ? (full ? wn_wgrad_kernel<2, 3, true> : wn_wgrad_kernel<2, 3, false>)
                                  : (full ? wn_wgrad_kernel<2, 2, true> : wn_wgrad_kernel<2, 2, false>);
@@ -443,7 +463,7 @@ extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0,
                                int64_t numel_a, void* stream) {
   FST_REQUIRE(dg && a && u0 && dw_in && dw_cond && workspace, "fst_wn_wgrad_in: null operand");
   const int served = fst_wn_wgrad_ok(0, B, L, n, h, dil);
-  FST_REQUIRE(served == 1 || (served == 2 && a_slack), "fst_wn_wgrad_in: unsupported shape B=%d L=%d n=%d h=%d dil=%d (needs L %% 16 == 0, "
+  FST_REQUIRE(served == 1 || (served == 2 && a_slack), "fst_wn_wgrad_in: unsupported shape B=%d L=%d n=%d h=%d dil=%d (needs L %% 32 == 0, "
               "n < 128, h <= 32, and dil %% 4 == 0 or — with 16 readable bytes either side of a — dil < 4)", B, L, n, h, dil);
   FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_in: B*n*L does not match the element count %lld of a", (long long)numel_a);
   FST_REQUIRE(B == 1 || u0_bs >= (int64_t)h * L, "fst_wn_wgrad_in: u0 batch stride %lld < h*L", (long long)u0_bs);
@@ -467,7 +487,7 @@ extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0,
 extern "C" int fst_wn_wgrad_rs(const float* d_a, const float* d_out, const float* ts, float* dw_rs, float* workspace,
                                int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a, void* stream) {
   FST_REQUIRE(d_out && ts && dw_rs && workspace && (last || d_a), "fst_wn_wgrad_rs: null operand");
-  FST_REQUIRE(fst_wn_wgrad_ok(1, B, L, n, 0, 4), "fst_wn_wgrad_rs: unsupported shape B=%d L=%d n=%d (needs L %% 16 == 0, n < 128)", B, L, n);
+  FST_REQUIRE(fst_wn_wgrad_ok(1, B, L, n, 0, 4), "fst_wn_wgrad_rs: unsupported shape B=%d L=%d n=%d (needs L %% 32 == 0, n < 128)", B, L, n);
   FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_rs: B*n*L does not match the element count %lld", (long long)numel_a);
   FST_REQUIRE(ww_al16(d_a) && ww_al16(d_out) && ww_al16(ts) && ww_al16(workspace), "fst_wn_wgrad_rs: operands must be 16-byte aligned");
   WwParams p = {};

@@ -716,7 +716,7 @@ class WNSpecs:
 
 def wn_wgrad_ok(kind: int, B: int, L: int, n: int, h: int, dil: int, a: Optional[Tensor] = None) -> bool:
     """Whether the time-as-k weight-gradient kernels of csrc/wn_wgrad.hip serve this layer (kind 0 = in_layer + cond_layer,
-    1 = res_skip): split-bf16 arithmetic, L % 16 == 0, n < 128, h <= 32; tap shifts that are not multiples of 4 samples
+    1 = res_skip): split-bf16 arithmetic, L % 32 == 0, n < 128, h <= 32; tap shifts that are not multiples of 4 samples
     (dilation 1, 2) need 16 readable bytes either side of ``a`` (``empty_with_slack``).  Everything else stays on fst_conv_wgrad."""
     if MATH != "bf16x3" or os.environ.get("FST_WN_WGRAD", "1") == "0":
         return False
@@ -1160,8 +1160,8 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
                 S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul, out0=g_rs_w[i])      # (its bias gradient is d_out_sum, in place)
             else:
                 S.rs[i].grad_w(x_rs, None, d_a, d_out, msplit=n, x0_mul_off=mul, out0=g_rs_w[i])
-                if part_d is None and d_a_sum is None:   # not left behind by a fused data-gradient launch: one pass over d_a
-                    row_sum(d_a, out=d_rs_b_all[i, :n])
+            if not last and part_d is None and d_a_sum is None:   # Σ d_a not left behind by a fused data-gradient launch
+                row_sum(d_a, out=d_rs_b_all[i, :n])
         # ---- through the gate
         dg = torch.empty(B, 2 * n, L, device=dev, dtype=torch.float32)
         dg_sum = None

@@ -263,7 +263,7 @@ int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, 
  *   fst_wn_wgrad_in   dw_in[m][c][τ] = Σ_{b,t} dg[b,m,t]·a[b,c,t+(τ−1)·dil]   ([2n][n][3]),   dw_cond[m][c] = Σ dg[b,m,t]·u0[b,c,t]  ([2n][h])
  *   fst_wn_wgrad_rs   dw_rs[m][c] = Σ_{b,t} [d_a ; d_out][b,m,t]·(t·s)[b,c,t]  ([2n][n]; last layer: d_a NULL, [n][n]) — acts = t·s is
  *                     re-formed from the gate halves ts [B][2n][L] the fused forward saved
- * kind 0 = in_layer + cond_layer, 1 = res_skip.  fst_wn_wgrad_ok: 1 when the shape is served (L % 16 == 0, n < 128, h <= 32 and for
+ * kind 0 = in_layer + cond_layer, 1 = res_skip.  fst_wn_wgrad_ok: 1 when the shape is served (L % 32 == 0, n < 128, h <= 32 and for
  * kind 0 dil % 4 == 0); 2 (kind 0, dil < 4) when it is served provided the caller guarantees 16 readable bytes in front of and
  * behind `a` (a_slack: the 16-byte pieces of a shifted tap start up to 3 samples outside a row); 0: the caller uses fst_conv_wgrad.
  * workspace: fst_wn_wgrad_workspace_floats(...) floats, written. */

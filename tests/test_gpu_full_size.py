@@ -202,7 +202,7 @@ def test_joint_step_gradients_at_batch_32(arithmetic):
 
 
 @pytest.mark.parametrize("n,h,Bq,L,dil", [(120, 25, 256, 512, 4), (120, 25, 256, 512, 128), (120, 25, 64, 1024, 16),
-                                          (120, 25, 256, 512, 1), (120, 25, 256, 512, 2), (33, 31, 3, 48, 1), (8, 3, 2, 16, 2), (16, 5, 2, 64, 3),
+                                          (120, 25, 256, 512, 1), (120, 25, 256, 512, 2), (33, 31, 3, 64, 1), (8, 3, 2, 32, 2), (16, 5, 2, 64, 3),
                                           (8, 3, 3, 64, 4), (33, 31, 2, 96, 8), (127, 32, 2, 128, 4), (16, 16, 5, 32, 8),
                                           (120, 25, 1, 32, 4)])      # one tile in all: most workgroups have nothing to do
 def test_time_as_k_weight_gradient_kernels(n, h, Bq, L, dil):
@@ -217,7 +217,7 @@ def test_time_as_k_weight_gradient_kernels(n, h, Bq, L, dil):
     dgd = _rnd(g, Bq, 2 * n, L)
     assert ops.wn_wgrad_ok(0, Bq, L, n, h, dil, a) and ops.wn_wgrad_ok(1, Bq, L, n, h, dil)
     assert ops.wn_wgrad_ok(0, Bq, L, n, h, 2, a) and not ops.wn_wgrad_ok(0, Bq, L, n, h, 2, a.clone())   # no slack: not served
-    assert not ops.wn_wgrad_ok(0, Bq, L, n, h, 6, a) and not ops.wn_wgrad_ok(0, Bq, L + 4, n, h, dil, a)
+    assert not ops.wn_wgrad_ok(0, Bq, L, n, h, 6, a) and not ops.wn_wgrad_ok(0, Bq, L + 16, n, h, dil, a)
     u0 = _rnd(g, Bq, 2 * h, L)[:, :h]                                   # a channel-slice view, as the flow passes it
     dw_in, dw_cond = torch.full((2 * n, n, 3), 7.0, device=DEV), torch.full((2 * n, h, 1), 7.0, device=DEV)
     ops.wn_wgrad_in(dgd, a, u0, dw_in, dw_cond, n, h, dil)
