@@ -70,7 +70,8 @@ __device__ __forceinline__ void ww_split_pair(float a, float b, unsigned& hi, un
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, ww_bf16x2));
 }
 
-__device__ __forceinline__ void ww_split8(const float4& v0, const float4& v1, ww_bf16x8& hi, ww_bf16x8& lo) {
+template <class V4>
+__device__ __forceinline__ void ww_split8(const V4& v0, const V4& v1, ww_bf16x8& hi, ww_bf16x8& lo) {
   ww_u32x4 h, l;
   unsigned hh, ll;
   ww_split_pair(v0.x, v0.y, hh, ll); h[0] = hh; l[0] = ll;
@@ -79,6 +80,27 @@ __device__ __forceinline__ void ww_split8(const float4& v0, const float4& v1, ww
   ww_split_pair(v1.z, v1.w, hh, ll); h[3] = hh; l[3] = ll;
   hi = __builtin_bit_cast(ww_bf16x8, h);
   lo = __builtin_bit_cast(ww_bf16x8, l);
+}
+
+// LDS fragment reads as inline asm.  hipcc's wait-count pass cannot tell ring slots apart: in front of the first compiler-visible
+// LDS read that follows an LDS-DMA issue it places s_waitcnt vmcnt(0) — which drained both rings every stage (the DMA of the
+// next stages, issued a few instructions earlier, had to land before the current stage could be multiplied: 139 µs).  The pass
+// does not look inside asm; ordering is by the counted vmcnt + barrier at the top of the stage, and the reads are retired by
+// the explicit lgkmcnt wait + scheduling barrier below.
+typedef float ww_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ww_f32x4 ww_lds_read16(const char* p) {
+  ww_f32x4 v;
+  const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ void ww_lds_zero4(char* p) {
+  const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)p);
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(0.0f) : "memory");
+}
+__device__ __forceinline__ void ww_lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);                       // nothing that consumes a read may be hoisted above the wait
 }
 
 template <int N>
@@ -96,8 +118,12 @@ __device__ __forceinline__ int ww_dma_row(int i, int lane) { return 8 * i + ((la
 // which tensor row / piece a lane of a k-row DMA instruction fetches → (address for batch 0, t0 = 0; batch stride; first sample)
 struct WwSrc { const float* p; int bs, t; };
 
-// FULL: every output-row block and every k-row block of every group is live: no block tests in the inner loop.
-template <int MT, int KT, bool FULL>
+// FULL: every output-row block and every k-row block of every group is live: no block tests in the inner loop.  MUL: product
+// operand (every k-row fragment is the product of two staged rows).  NE: leftover k-rows accumulated on the VALU (0 or 1).
+// The k-step body is straight-line code (no run-time branches: the compiler then issues all of a k-step's fragment reads up
+// front and waits for them one by one as the splits consume them; with uniform branches around the optional parts it read,
+// waited, split and multiplied fragment by fragment — 139 µs instead of the ring's rate).
+template <int MT, int KT, bool FULL, bool MUL, int NE>
 __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   extern __shared__ __attribute__((aligned(16))) char ww_lds[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -196,15 +222,15 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
     for (int j = 0; j < KT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ev[MT][2];
+  float ev[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) ev[i][0] = ev[i][1] = 0.f;
+  for (int i = 0; i < MT; ++i) ev[i] = 0.f;
 
   const int tile_begin = (int)(((long long)blockIdx.x * p.n_tiles) / p.ksplit);
   const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.n_tiles) / p.ksplit);
   const int m_blocks = (p.M + 31) >> 5;
   const int k_blocks_here = min(2 * KT, ((p.K_main + 31) >> 5) - g * 2 * KT);   // live k-row blocks of this group
-  const bool do_extra = g == 0 && wk == 0 && p.n_extra > 0;
+  const bool do_extra = NE > 0 && g == 0 && wk == 0;
 
   // fragment addressing: row block·32 + l31 (LDS row l31 ^ ((l31 >> 3) & 1) of the block), pieces 4·ks + 2·half and the next
   const int row_l = (l31 ^ ((l31 >> 3) & 1)) << 7;
@@ -251,9 +277,9 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
           if (kk < p.K_main && (sh & 3) != 0) {
             char* rowp = xring + xslot * xslot_bytes + ((tid ^ ((tid >> 3) & 1)) << 7);
             if (at_start && sh < 0 && sh > -4)             // samples t0 + sh + j < 0 of piece 0
-              for (int j = 0; j < -sh; ++j) reinterpret_cast<float*>(rowp + (((0 ^ tid) & 7) << 4))[j] = 0.f;
+              for (int j = 0; j < -sh; ++j) ww_lds_zero4(rowp + (((0 ^ tid) & 7) << 4) + 4 * j);
             if (at_end && sh > 0 && sh < 4)                // samples t0 + sh + 28 + j >= L of piece 7
-              for (int j = 4 - sh; j < 4; ++j) reinterpret_cast<float*>(rowp + (((7 ^ tid) & 7) << 4))[j] = 0.f;
+              for (int j = 4 - sh; j < 4; ++j) ww_lds_zero4(rowp + (((7 ^ tid) & 7) << 4) + 4 * j);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zeroing stores; NOT __syncthreads(): its fence would drain the ring
@@ -262,42 +288,41 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      ww_bf16x8 ah[MT], al[MT];
-      float4 araw[MT][2];
+      // every fragment read of the k-step first ...
+      ww_f32x4 araw[MT][2], braw[KT][2], craw[KT][2], eraw[2];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const char* ap = dsl + a_off + ((i * 32) << 7);
-        araw[i][0] = *reinterpret_cast<const float4*>(ap + pc[ks][0]);
-        araw[i][1] = *reinterpret_cast<const float4*>(ap + pc[ks][1]);
-        ww_split8(araw[i][0], araw[i][1], ah[i], al[i]);
-      }
-      if (do_extra) {
-        // leftover k-rows on the VALU: every lane of a half reads the same 8 samples of the row (a broadcast), lane = output row
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          if (e >= p.n_extra) break;
-          const char* ep = xsl + e_off + (e << 7);
-          const float4 x0 = *reinterpret_cast<const float4*>(ep + ((((4 * ks + 2 * half) ^ e) & 7) << 4));
-          const float4 x1 = *reinterpret_cast<const float4*>(ep + ((((4 * ks + 2 * half + 1) ^ e) & 7) << 4));
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-            ev[i][e] += (araw[i][0].x * x0.x + araw[i][0].y * x0.y) + (araw[i][0].z * x0.z + araw[i][0].w * x0.w) +
-                        (araw[i][1].x * x1.x + araw[i][1].y * x1.y) + (araw[i][1].z * x1.z + araw[i][1].w * x1.w);
-        }
+        araw[i][0] = ww_lds_read16(ap + pc[ks][0]);
+        araw[i][1] = ww_lds_read16(ap + pc[ks][1]);
       }
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
-        if (!FULL && wk * KT + j >= k_blocks_here) break;  // wave-uniform: blocks beyond K hold zeros
         const char* bp = xsl + x_off + ((j * 32) << 7);
-        float4 b0 = *reinterpret_cast<const float4*>(bp + pc[ks][0]);
-        float4 b1 = *reinterpret_cast<const float4*>(bp + pc[ks][1]);
-        if (p.mul) {                                       // kernel argument: uniform
+        braw[j][0] = ww_lds_read16(bp + pc[ks][0]);
+        braw[j][1] = ww_lds_read16(bp + pc[ks][1]);
+        if constexpr (MUL) {
           const char* qp = xsl + xp_off + ((j * 32) << 7);
-          const float4 c0 = *reinterpret_cast<const float4*>(qp + pc[ks][0]);
-          const float4 c1 = *reinterpret_cast<const float4*>(qp + pc[ks][1]);
-          b0.x *= c0.x; b0.y *= c0.y; b0.z *= c0.z; b0.w *= c0.w;
-          b1.x *= c1.x; b1.y *= c1.y; b1.z *= c1.z; b1.w *= c1.w;
+          craw[j][0] = ww_lds_read16(qp + pc[ks][0]);
+          craw[j][1] = ww_lds_read16(qp + pc[ks][1]);
         }
+      }
+      if constexpr (NE > 0) {
+        // the leftover k-row: every lane of a half reads the same 8 samples (a broadcast); LDS row 0 of its octet, unswizzled
+        const char* ep = xsl + e_off;
+        eraw[0] = ww_lds_read16(ep + ((4 * ks + 2 * half) << 4));
+        eraw[1] = ww_lds_read16(ep + ((4 * ks + 2 * half + 1) << 4));
+      }
+      ww_lds_wait();
+      // ... then split and multiply as they arrive
+      ww_bf16x8 ah[MT], al[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ww_split8(araw[i][0], araw[i][1], ah[i], al[i]);
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        if (!FULL && wk * KT + j >= k_blocks_here) break;  // wave-uniform: blocks beyond K hold zeros
+        ww_f32x4 b0 = braw[j][0], b1 = braw[j][1];
+        if constexpr (MUL) { b0 *= craw[j][0]; b1 *= craw[j][1]; }
         ww_bf16x8 bh, bl;
         ww_split8(b0, b1, bh, bl);
 #pragma unroll
@@ -307,6 +332,13 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
         }
+      }
+      if constexpr (NE > 0) {
+        // leftover k-row on the VALU (lane = output row; every wave does it, the k-half-0 waves of group 0 store it)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          ev[i] += (araw[i][0].x * eraw[0].x + araw[i][0].y * eraw[0].y) + (araw[i][0].z * eraw[0].z + araw[i][0].w * eraw[0].w) +
+                   (araw[i][1].x * eraw[1].x + araw[i][1].y * eraw[1].y) + (araw[i][1].z * eraw[1].z + araw[i][1].w * eraw[1].w);
       }
     }
     dslot = dslot == WW_ND - 1 ? 0 : dslot + 1;
@@ -331,11 +363,8 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       if (wm * MT + i >= m_blocks) break;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float s = ev[i][e] + __shfl_xor(ev[i][e], 32, 64);
-        if (half == 0 && e < p.n_extra) p.slab_extra[((long long)blockIdx.x * WW_MROWS + (wm * MT + i) * 32 + l31) * 2 + e] = s;
-      }
+      const float sv = ev[i] + __shfl_xor(ev[i], 32, 64);
+      if (half == 0) p.slab_extra[((long long)blockIdx.x * WW_MROWS + (wm * MT + i) * 32 + l31) * 2] = sv;
     }
   }
 }
@@ -407,7 +436,7 @@ static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams*
   p->M = kind == 0 ? 2 * n : (last ? n : 2 * n);
   p->K = kind == 0 ? 3 * n + h : n;
   const int rem = p->K & 31;
-  p->n_extra = (kind == 0 && rem >= 1 && rem <= 2) ? rem : 0;      // one or two k-rows past a multiple of 32: VALU rows
+  p->n_extra = (kind == 0 && rem == 1) ? 1 : 0;                    // one k-row past a multiple of 32: a VALU row
   p->K_main = p->n_extra ? p->K - rem : p->K;
   p->xr = 32 * 2 * KT;
   const int kb = (p->K_main + 31) / 32;
@@ -448,8 +477,13 @@ static int ww_launch(WwParams& p, int KT, void* stream) {
   const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + (size_t)WW_NX * p.RX * 128;
   FST_REQUIRE(lds <= 160 * 1024 && (p.RX >> 3) <= 8 * WW_MAX_NX, "fst_wn_wgrad: %d staged k-rows per stage do not fit (LDS %zu B)", p.RX, lds);
   const bool full = (p.M + 31) / 32 == 8 && ((p.K_main + 31) / 32) % (2 * KT) == 0;
-  void (*fn)(WwParams) = KT == 3 ? (full ? wn_wgrad_kernel<2, 3, true> : wn_wgrad_kernel<2, 3, false>)
-                                 : (full ? wn_wgrad_kernel<2, 2, true> : wn_wgrad_kernel<2, 2, false>);
+  void (*fn)(WwParams);
+  if (KT == 3) {
+    if (p.n_extra) fn = full ? wn_wgrad_kernel<2, 3, true, false, 1> : wn_wgrad_kernel<2, 3, false, false, 1>;
+    else fn = full ? wn_wgrad_kernel<2, 3, true, false, 0> : wn_wgrad_kernel<2, 3, false, false, 0>;
+  } else {
+    fn = full ? wn_wgrad_kernel<2, 2, true, true, 0> : wn_wgrad_kernel<2, 2, false, true, 0>;
+  }
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_wn_wgrad")) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
