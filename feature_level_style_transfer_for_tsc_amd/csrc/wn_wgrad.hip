@@ -23,6 +23,8 @@
 //     wn_wgrad_reduce_kernel adds the slabs in a fixed order and writes PyTorch layout: deterministic, no atomics.
 // Served: L % 32 == 0, n < 128 (M ≤ 256), h ≤ 32, tap shifts that are multiples of 4 samples (dil % 4 == 0), 16-byte aligned
 // tensors; everything else stays on conv_wgrad_kernel (fst_wn_wgrad_ok tells).
+#include <stdlib.h>
+
 #include "fst_common.h"
 
 typedef __bf16 ww_bf16x8 __attribute__((ext_vector_type(8)));
@@ -57,6 +59,8 @@ struct WwParams {
   int n_groups, ksplit, B, L, tiles_per_seq, n_tiles;
   int RX;               // staged rows of a k-row slot: xr·(1 + mul) (+ 8 for the leftover rows), a multiple of 8
   int misaligned;       // some tap shift is not a multiple of 4 samples (|shift| < 4): straddling pieces are patched in LDS
+  int exp;              // diagnostics (FST_WW_EXP, timing only, wrong results): 1 every LDS-DMA piece from the zero block, 2 no k-step
+                        // arithmetic (no LDS reads, splits, MFMAs), 4 no LDS-DMA at all
   int Kcols;            // slab row length = n_groups·xr
   float* slab;          // [ksplit][256][Kcols]
   float* slab_extra;    // [ksplit][256][2]
@@ -97,6 +101,13 @@ __device__ __forceinline__ ww_f32x4 ww_lds_read16(const char* p) {
 __device__ __forceinline__ void ww_lds_zero4(char* p) {
   const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)p);
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(0.0f) : "memory");
+}
+// One LDS-DMA piece as inline asm too: with the builtin the same pass put s_waitcnt vmcnt(0) in front of the address arithmetic of
+// every piece but the first once the issues were spread between the MFMAs (each issue then waited for all earlier pieces to land).
+// M0 carries the wave-uniform LDS byte address; the 64 lanes' 16 bytes land at M0 + 16·lane.
+__device__ __forceinline__ void ww_dma16(const char* gsrc, char* lds_dst) {
+  const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(addr) : "memory", "m0");
 }
 __device__ __forceinline__ void ww_lds_wait() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -186,33 +197,51 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
     }
   }
 
+  // (misaligned taps) the tap shift of the staged k-row `tid` of this group, for the boundary patch below; 0 = nothing to patch
+  int patch_sh = 0;
+  if (p.misaligned && tid < p.xr) {
+    const int kk = g * p.xr + tid;
+    int c0 = kk, si = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (si + 1 < p.n_x && c0 >= p.x[si].rows) { c0 -= p.x[si].rows; ++si; }
+    const int sh = si == 0 ? p.x[0].shift : (si == 1 ? p.x[1].shift : (si == 2 ? p.x[2].shift : p.x[3].shift));
+    if (kk < p.K_main && (sh & 3) != 0 && sh > -4 && sh < 4) patch_sh = sh;
+  }
+  // The tables above are per-lane selections of kernel arguments: the compiler reads some of them with vector loads, and — not
+  // seeing the inline-asm waits below — would make every first use inside the stage loop wait for vmcnt(0), i.e. for the whole
+  // LDS-DMA ring.  A wait it does see, here, retires them once.
+  __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), expcnt / lgkmcnt untouched
+
   auto tile_bt = [&](int tile, int& b, int& t0) {
     b = tile / p.tiles_per_seq;
     t0 = (tile - b * p.tiles_per_seq) * WW_TT;
   };
+  // one LDS-DMA piece: k-th dy instruction / k-th k-row instruction of this wave for the stage (b, t0) into the given slot
+  auto issue_dy1 = [&](int k, int b, int t0, int slot) {
+    if (p.exp & 4) return;
+    const bool ok = dsrc[k].p != nullptr && t0 + dsrc[k].t < L && !(p.exp & 1);
+    const char* src = ok ? reinterpret_cast<const char*>(dsrc[k].p + ((long long)b * dsrc[k].bs + t0)) : zero16;
+    ww_dma16(src, ww_lds + slot * dslot_bytes + (wave_s + 8 * k) * 1024);
+  };
+  auto issue_x1 = [&](int k, int b, int t0, int slot) {
+    if (k >= my_nx || (p.exp & 4)) return;                 // wave-uniform
+    const int t = t0 + xsrc[k].t;
+    const bool ok = xsrc[k].p != nullptr && t > -4 && t < L && !(p.exp & 1);   // the piece overlaps the sequence (a straddling one is patched)
+    const char* src = ok ? reinterpret_cast<const char*>(xsrc[k].p + ((long long)b * xsrc[k].bs + t0)) : zero16;
+    ww_dma16(src, xring + slot * xslot_bytes + (wave_s + 8 * k) * 1024);
+  };
   auto issue_dy = [&](int tile, int slot) {
     int b, t0;
     tile_bt(tile, b, t0);
-    char* const sl = ww_lds + slot * dslot_bytes;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const bool ok = dsrc[k].p != nullptr && t0 + dsrc[k].t < L;
-      const char* src = ok ? reinterpret_cast<const char*>(dsrc[k].p + ((long long)b * dsrc[k].bs + t0)) : zero16;
-      __builtin_amdgcn_global_load_lds(WW_GLOBAL_PTR(src), WW_LDS_VOID(sl + (wave_s + 8 * k) * 1024), 16, 0, 0);
-    }
+    for (int k = 0; k < 4; ++k) issue_dy1(k, b, t0, slot);
   };
   auto issue_x = [&](int tile, int slot) {
     int b, t0;
     tile_bt(tile, b, t0);
-    char* const sl = xring + slot * xslot_bytes;
 #pragma unroll
-    for (int k = 0; k < WW_MAX_NX; ++k) {
-      if (k >= my_nx) break;                              // wave-uniform
-      const int t = t0 + xsrc[k].t;
-      const bool ok = xsrc[k].p != nullptr && t > -4 && t < L;   // the piece overlaps the sequence (a straddling one is patched below)
-      const char* src = ok ? reinterpret_cast<const char*>(xsrc[k].p + ((long long)b * xsrc[k].bs + t0)) : zero16;
-      __builtin_amdgcn_global_load_lds(WW_GLOBAL_PTR(src), WW_LDS_VOID(sl + (wave_s + 8 * k) * 1024), 16, 0, 0);
-    }
+    for (int k = 0; k < WW_MAX_NX; ++k) issue_x1(k, b, t0, slot);
   };
 
   f32x16 acc[MT][KT];
@@ -255,8 +284,20 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   for (int c = 0; c < n_st; ++c) {
     if (c + 1 < n_st) ww_wait_vmcnt<4>(); else ww_wait_vmcnt<0>();   // (a wave issues 4 dy pieces per stage)
     __builtin_amdgcn_s_barrier();                          // everyone's pieces of stage c have landed; stage c - 1 has been read by all
-    if (c + 1 < n_st) issue_x(tile_begin + c + 1, xslot ^ 1);
-    if (c + 2 < n_st) issue_dy(tile_begin + c + 2, dslot >= 1 ? dslot - 1 : 2);
+    // The pieces of x(c+1), then of dy(c+2), are issued ONE AT A TIME between the MFMA groups below (issue order unchanged, so
+    // the counted wait stands): an LDS-DMA issue blocks its wave for 40-150 cycles while the CU's one address path takes the
+    // instruction — all eight waves issuing their 7-8 pieces back to back after the barrier cost the whole CU ~1 µs per stage in
+    // which nothing multiplied (cost removal: arithmetic 64 µs + LDS-DMA 36 µs = the 97 µs measured); spread out, a wave's blocked
+    // issue sits beside its SIMD partner's MFMAs.
+    const bool have_x = c + 1 < n_st, have_dy = c + 2 < n_st;
+    int nb = 0, nt0 = 0, db = 0, dt0 = 0;
+    if (have_x) tile_bt(tile_begin + c + 1, nb, nt0);
+    if (have_dy) tile_bt(tile_begin + c + 2, db, dt0);
+    const int x_next = xslot ^ 1, d_next = dslot >= 1 ? dslot - 1 : 2;
+    auto issue_pos = [&](int pos) {                        // pos 0..4: k-row pieces, 5..8: dy pieces
+      if (pos < WW_MAX_NX) { if (have_x) issue_x1(pos, nb, nt0, x_next); }
+      else if (pos < WW_MAX_NX + 4) { if (have_dy) issue_dy1(pos - WW_MAX_NX, db, dt0, d_next); }
+    };
     const char* const dsl = ww_lds + dslot * dslot_bytes;
     const char* const xsl = xring + xslot * xslot_bytes;
     if (p.misaligned) {                                    // kernel argument: uniform
@@ -267,25 +308,18 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
       tile_bt(tile_begin + c, bq, t0);
       const bool at_start = t0 == 0, at_end = t0 + WW_TT >= L;
       if (at_start || at_end) {
-        if (tid < p.xr) {
-          const int kk = g * p.xr + tid;
-          int c0 = kk, si = 0;
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            if (si + 1 < p.n_x && c0 >= p.x[si].rows) { c0 -= p.x[si].rows; ++si; }
-          const int sh = si == 0 ? p.x[0].shift : (si == 1 ? p.x[1].shift : (si == 2 ? p.x[2].shift : p.x[3].shift));
-          if (kk < p.K_main && (sh & 3) != 0) {
-            char* rowp = xring + xslot * xslot_bytes + ((tid ^ ((tid >> 3) & 1)) << 7);
-            if (at_start && sh < 0 && sh > -4)             // samples t0 + sh + j < 0 of piece 0
-              for (int j = 0; j < -sh; ++j) ww_lds_zero4(rowp + (((0 ^ tid) & 7) << 4) + 4 * j);
-            if (at_end && sh > 0 && sh < 4)                // samples t0 + sh + 28 + j >= L of piece 7
-              for (int j = 4 - sh; j < 4; ++j) ww_lds_zero4(rowp + (((7 ^ tid) & 7) << 4) + 4 * j);
-          }
+        if (patch_sh != 0) {
+          char* rowp = xring + xslot * xslot_bytes + ((tid ^ ((tid >> 3) & 1)) << 7);
+          if (at_start && patch_sh < 0)                      // samples t0 + sh + j < 0 of piece 0
+            for (int j = 0; j < -patch_sh; ++j) ww_lds_zero4(rowp + (((0 ^ tid) & 7) << 4) + 4 * j);
+          if (at_end && patch_sh > 0)                        // samples t0 + sh + 28 + j >= L of piece 7
+            for (int j = 4 - patch_sh; j < 4; ++j) ww_lds_zero4(rowp + (((7 ^ tid) & 7) << 4) + 4 * j);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zeroing stores; NOT __syncthreads(): its fence would drain the ring
         __builtin_amdgcn_s_barrier();
       }
     }
+    if (!(p.exp & 2))
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       // every fragment read of the k-step first ...
@@ -314,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
         eraw[1] = ww_lds_read16(ep + ((4 * ks + 2 * half + 1) << 4));
       }
       ww_lds_wait();
+      issue_pos(5 * ks);
       // ... then split and multiply as they arrive
       ww_bf16x8 ah[MT], al[MT];
 #pragma unroll
@@ -332,7 +367,10 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
         }
+        issue_pos(5 * ks + 1 + j);
       }
+      if constexpr (KT < 3) issue_pos(5 * ks + 3);
+      issue_pos(5 * ks + 4);
       if constexpr (NE > 0) {
         // leftover k-row on the VALU (lane = output row; every wave does it, the k-half-0 waves of group 0 store it)
 #pragma unroll
@@ -474,6 +512,8 @@ extern "C" int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, 
 }
 
 static int ww_launch(WwParams& p, int KT, void* stream) {
+  static const int exp_env = getenv("FST_WW_EXP") ? atoi(getenv("FST_WW_EXP")) : 0;
+  p.exp = exp_env;
   const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + (size_t)WW_NX * p.RX * 128;
   FST_REQUIRE(lds <= 160 * 1024 && (p.RX >> 3) <= 8 * WW_MAX_NX, "fst_wn_wgrad: %d staged k-rows per stage do not fit (LDS %zu B)", p.RX, lds);
   const bool full = (p.M + 31) / 32 == 8 && ((p.K_main + 31) / 32) % (2 * KT) == 0;
