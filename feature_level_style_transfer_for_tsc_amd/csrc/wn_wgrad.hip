@@ -98,6 +98,10 @@ __device__ __forceinline__ ww_f32x4 ww_lds_read16(const char* p) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+__device__ __forceinline__ void ww_lds_write16(char* p, const ww_u32x4& v) {
+  const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)p);
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
 __device__ __forceinline__ void ww_lds_zero4(char* p) {
   const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)p);
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(0.0f) : "memory");
@@ -114,6 +118,16 @@ __device__ __forceinline__ void ww_lds_wait() {
   __builtin_amdgcn_sched_barrier(0);                       // nothing that consumes a read may be hoisted above the wait
 }
 
+// 8 consecutive samples (two raw 16-byte pieces) → their bf16 hi parts and lo parts, 16 bytes each
+template <class V4>
+__device__ __forceinline__ void ww_split8u(const V4& v0, const V4& v1, ww_u32x4& h, ww_u32x4& l) {
+  unsigned hh, ll;
+  ww_split_pair(v0.x, v0.y, hh, ll); h[0] = hh; l[0] = ll;
+  ww_split_pair(v0.z, v0.w, hh, ll); h[1] = hh; l[1] = ll;
+  ww_split_pair(v1.x, v1.y, hh, ll); h[2] = hh; l[2] = ll;
+  ww_split_pair(v1.z, v1.w, hh, ll); h[3] = hh; l[3] = ll;
+}
+
 template <int N>
 __device__ __forceinline__ void ww_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -125,6 +139,8 @@ __device__ __forceinline__ void ww_wait_vmcnt() {
 // rows are a multiple of 128 B apart.  An LDS-DMA instruction fills 8 LDS rows (1 KiB, lane-linear): lane → LDS row 8i + (lane >> 3),
 // piece slot lane & 7.
 __device__ __forceinline__ int ww_dma_row(int i, int lane) { return 8 * i + ((lane >> 3) ^ (i & 1)); }
+// byte offset of piece q of logical row r inside a slot
+__device__ __forceinline__ int ww_lds_off(int r, int q) { return ((r ^ ((r >> 3) & 1)) << 7) + (((q ^ r) & 7) << 4); }
 
 // which tensor row / piece a lane of a k-row DMA instruction fetches → (address for batch 0, t0 = 0; batch stride; first sample)
 struct WwSrc { const float* p; int bs, t; };
@@ -251,15 +267,13 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
     for (int j = 0; j < KT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ev[MT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) ev[i] = 0.f;
+  float ev[2] = {0.f, 0.f};                                // leftover k-row: partial dot products of this thread's two dy units
 
   const int tile_begin = (int)(((long long)blockIdx.x * p.n_tiles) / p.ksplit);
   const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.n_tiles) / p.ksplit);
   const int m_blocks = (p.M + 31) >> 5;
   const int k_blocks_here = min(2 * KT, ((p.K_main + 31) >> 5) - g * 2 * KT);   // live k-row blocks of this group
-  const bool do_extra = NE > 0 && g == 0 && wk == 0;
+  const bool do_extra = NE > 0 && g == 0;
 
   // fragment addressing: row block·32 + l31 (LDS row l31 ^ ((l31 >> 3) & 1) of the block), pieces 4·ks + 2·half and the next
   const int row_l = (l31 ^ ((l31 >> 3) & 1)) << 7;
@@ -319,11 +333,59 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
         __builtin_amdgcn_s_barrier();
       }
     }
+    // ---- split pass: every staged 8-sample unit (two raw 16-byte pieces of a row) is split ONCE per workgroup, in place, into
+    // its bf16 hi parts (written over the first piece) and lo parts (over the second) — not once per consuming wave (each dy
+    // fragment is consumed by 2 waves, each k-row fragment by 4: 280 VALU instructions per wave and stage against 36 MFMAs).
+    // Thread t owns the dy units t and t + 512 (rows t>>2 and 128 + (t>>2), unit t&3) and the k-row units t (and t + 512).
+    if (!(p.exp & 2)) {
+      char* const dw = ww_lds + dslot * dslot_bytes;
+      char* const xw = xring + xslot * xslot_bytes;
+      const int u = tid & 3, r0 = tid >> 2;
+      ww_f32x4 e0, e1;
+      if constexpr (NE > 0) {                              // the leftover k-row's 8 samples of this unit (raw, never split)
+        e0 = ww_lds_read16(xw + e_off + ((2 * u) << 4));
+        e1 = ww_lds_read16(xw + e_off + ((2 * u + 1) << 4));
+      }
+      ww_f32x4 d[2][2], xq[2][2], xm[2][2];
+      char* da[2][2]; char* xa[2][2];
+      const int nxu = (p.xr * 4 > 512 + tid) ? 2 : 1;      // k-row units of this thread: rows r0 and (if it exists) 128 + r0
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = r0 + 128 * i;
+        da[i][0] = dw + ww_lds_off(r, 2 * u); da[i][1] = dw + ww_lds_off(r, 2 * u + 1);
+        d[i][0] = ww_lds_read16(da[i][0]); d[i][1] = ww_lds_read16(da[i][1]);
+        xa[i][0] = xw + ww_lds_off(r, 2 * u); xa[i][1] = xw + ww_lds_off(r, 2 * u + 1);
+        if (i < nxu && r < p.xr) {
+          xq[i][0] = ww_lds_read16(xa[i][0]); xq[i][1] = ww_lds_read16(xa[i][1]);
+          if constexpr (MUL) {
+            xm[i][0] = ww_lds_read16(xa[i][0] + (p.xr << 7)); xm[i][1] = ww_lds_read16(xa[i][1] + (p.xr << 7));
+          }
+        }
+      }
+      ww_lds_wait();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = r0 + 128 * i;
+        if constexpr (NE > 0)
+          ev[i] += (d[i][0].x * e0.x + d[i][0].y * e0.y) + (d[i][0].z * e0.z + d[i][0].w * e0.w) +
+                   (d[i][1].x * e1.x + d[i][1].y * e1.y) + (d[i][1].z * e1.z + d[i][1].w * e1.w);
+        ww_u32x4 h4, l4;
+        ww_split8u(d[i][0], d[i][1], h4, l4);
+        ww_lds_write16(da[i][0], h4); ww_lds_write16(da[i][1], l4);
+        if (i < nxu && r < p.xr) {
+          if constexpr (MUL) { xq[i][0] *= xm[i][0]; xq[i][1] *= xm[i][1]; }
+          ww_split8u(xq[i][0], xq[i][1], h4, l4);
+          ww_lds_write16(xa[i][0], h4); ww_lds_write16(xa[i][1], l4);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---- multiply: fragments are read as they stand (hi = first piece, lo = second piece of the lane's unit)
     if (!(p.exp & 2))
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      // every fragment read of the k-step first ...
-      ww_f32x4 araw[MT][2], braw[KT][2], craw[KT][2], eraw[2];
+      ww_f32x4 araw[MT][2], braw[KT][2];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const char* ap = dsl + a_off + ((i * 32) << 7);
@@ -335,49 +397,25 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
         const char* bp = xsl + x_off + ((j * 32) << 7);
         braw[j][0] = ww_lds_read16(bp + pc[ks][0]);
         braw[j][1] = ww_lds_read16(bp + pc[ks][1]);
-        if constexpr (MUL) {
-          const char* qp = xsl + xp_off + ((j * 32) << 7);
-          craw[j][0] = ww_lds_read16(qp + pc[ks][0]);
-          craw[j][1] = ww_lds_read16(qp + pc[ks][1]);
-        }
-      }
-      if constexpr (NE > 0) {
-        // the leftover k-row: every lane of a half reads the same 8 samples (a broadcast); LDS row 0 of its octet, unswizzled
-        const char* ep = xsl + e_off;
-        eraw[0] = ww_lds_read16(ep + ((4 * ks + 2 * half) << 4));
-        eraw[1] = ww_lds_read16(ep + ((4 * ks + 2 * half + 1) << 4));
       }
       ww_lds_wait();
       issue_pos(5 * ks);
-      // ... then split and multiply as they arrive
-      ww_bf16x8 ah[MT], al[MT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) ww_split8(araw[i][0], araw[i][1], ah[i], al[i]);
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
         if (!FULL && wk * KT + j >= k_blocks_here) break;  // wave-uniform: blocks beyond K hold zeros
-        ww_f32x4 b0 = braw[j][0], b1 = braw[j][1];
-        if constexpr (MUL) { b0 *= craw[j][0]; b1 *= craw[j][1]; }
-        ww_bf16x8 bh, bl;
-        ww_split8(b0, b1, bh, bl);
+        const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[j][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[j][1]);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           if (!FULL && wm * MT + i >= m_blocks) break;     // wave-uniform
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+          const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[i][1]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
         }
         issue_pos(5 * ks + 1 + j);
       }
       if constexpr (KT < 3) issue_pos(5 * ks + 3);
       issue_pos(5 * ks + 4);
-      if constexpr (NE > 0) {
-        // leftover k-row on the VALU (lane = output row; every wave does it, the k-half-0 waves of group 0 store it)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-          ev[i] += (araw[i][0].x * eraw[0].x + araw[i][0].y * eraw[0].y) + (araw[i][0].z * eraw[0].z + araw[i][0].w * eraw[0].w) +
-                   (araw[i][1].x * eraw[1].x + araw[i][1].y * eraw[1].y) + (araw[i][1].z * eraw[1].z + araw[i][1].w * eraw[1].w);
-      }
     }
     dslot = dslot == WW_ND - 1 ? 0 : dslot + 1;
     xslot ^= 1;
@@ -398,11 +436,13 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
     }
   }
   if (do_extra) {
+    // thread t holds the sums of unit t&3 of the dy rows t>>2 and 128 + (t>>2): the four units of a row sit in adjacent lanes
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if (wm * MT + i >= m_blocks) break;
-      const float sv = ev[i] + __shfl_xor(ev[i], 32, 64);
-      if (half == 0) p.slab_extra[((long long)blockIdx.x * WW_MROWS + (wm * MT + i) * 32 + l31) * 2] = sv;
+    for (int i = 0; i < 2; ++i) {
+      float sv = ev[i];
+      sv += __shfl_xor(sv, 1, 64);
+      sv += __shfl_xor(sv, 2, 64);
+      if ((tid & 3) == 0) p.slab_extra[((long long)blockIdx.x * WW_MROWS + (tid >> 2) + 128 * i) * 2] = sv;
     }
   }
 }
@@ -424,14 +464,18 @@ __device__ __forceinline__ void ww_scatter(const WwParams& p, int m, int kk, flo
   w[(long long)m * sm + (long long)c * sc + off] = v;
 }
 
-__global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(WwParams p) {
-  __shared__ float4 part[4][64];
-  const int m = blockIdx.y, cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int kk0 = blockIdx.x * 256 + cx * 4;
+__global__ __launch_bounds__(1024) void wn_wgrad_reduce_kernel(WwParams p) {
+  // 1024 threads = 256 quads of 4 consecutive slab floats (4 KiB contiguous per slab: the [m][Kcols] rows follow each other) x 4
+  // slab groups; eight 16-byte loads in flight per thread
+  __shared__ float4 part[3][256];
+  const int cx = threadIdx.x & 255, sg = threadIdx.x >> 8;
+  const long long e0 = ((long long)blockIdx.x * 256 + cx) * 4;          // first of this thread's 4 floats in the [M][Kcols] plane
+  const long long plane = (long long)p.M * p.Kcols;
+  const bool live = e0 < plane;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (kk0 < p.Kcols) {
+  if (live) {
     const long long st = (long long)WW_MROWS * p.Kcols;
-    const float* q = p.slab + (long long)m * p.Kcols + kk0;
+    const float* q = p.slab + e0;
     int sl = sg;
     for (; sl + 28 < p.ksplit; sl += 32) {
       float4 v[8];
@@ -445,23 +489,26 @@ __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(WwParams p) {
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   }
-  part[sg][cx] = s;
+  if (sg > 0) part[sg - 1][cx] = s;
   __syncthreads();
-  if (sg == 0 && kk0 < p.Kcols) {
-    float4 t = part[0][cx];
+  if (sg == 0 && live) {
 #pragma unroll
-    for (int g2 = 1; g2 < 4; ++g2) { const float4 o = part[g2][cx]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-    const float tv[4] = {t.x, t.y, t.z, t.w};
+    for (int g2 = 0; g2 < 3; ++g2) { const float4 o = part[g2][cx]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    const int m = (int)(e0 / p.Kcols), kk0 = (int)(e0 - (long long)m * p.Kcols);
+    const float tv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (kk0 + j < p.K_main) ww_scatter(p, m, kk0 + j, tv[j]);
   }
-  // the leftover k-rows (VALU sums): the last column block's idle slab-group-1 threads take them
-  if (blockIdx.x == gridDim.x - 1 && sg == 1 && cx < p.n_extra && p.K_main < p.K) {
-    const float* q = p.slab_extra + (long long)m * 2 + cx;
-    float e = 0.f;
-    for (int sl = 0; sl < p.ksplit; ++sl) e += q[(long long)sl * WW_MROWS * 2];
-    ww_scatter(p, m, p.K_main + cx, e);
+  // the leftover k-row (VALU sums): slab group 1 of the first workgroups takes it, one output row per thread
+  if (sg == 1 && p.n_extra > 0) {
+    const int m = blockIdx.x * 256 + cx;
+    if (m < p.M) {
+      const float* q = p.slab_extra + (long long)m * 2;
+      float e = 0.f;
+      for (int sl = 0; sl < p.ksplit; ++sl) e += q[(long long)sl * WW_MROWS * 2];
+      ww_scatter(p, m, p.K_main, e);
+    }
   }
 }
 
@@ -527,7 +574,8 @@ static int ww_launch(WwParams& p, int KT, void* stream) {
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_wn_wgrad")) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3((unsigned)((p.Kcols + 255) / 256), (unsigned)p.M), dim3(256), 0, (hipStream_t)stream, p);
+  const long long quads = ((long long)p.M * p.Kcols + 3) / 4;
+  hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(1024), 0, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }
