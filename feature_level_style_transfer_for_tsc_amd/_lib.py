@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
@@ -58,8 +58,9 @@ _SIGNATURES = {
     "fst_adam_multi": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_float, c_float, c_float, c_float, c_void_p]),
     "fst_wn_wgrad_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "fst_wn_wgrad_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "fst_wn_wgrad_in": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
-    "fst_wn_wgrad_rs": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_wn_wgrad_in": (c_int, [_P, _P, _P, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
+                                c_void_p]),
+    "fst_wn_wgrad_rs": (c_int, [_P, _P, _P, c_int, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_fold_fwd": (c_int, [_P, c_int, _P, _P, c_void_p]),
     "fst_wn_fold_bwd": (c_int, [_P, c_int, _P, _P, _P, c_void_p]),
     "fst_logdet_inv": (c_int, [_P, c_int, _P, _P, c_void_p]),

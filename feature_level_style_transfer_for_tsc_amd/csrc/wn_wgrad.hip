@@ -42,8 +42,10 @@ typedef unsigned ww_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __attribute__((aligned(16))) float ww_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
+#define WW_MAX_SETS 3
 struct WwSeg {
-  const float* ptr;     // rows of a [B][.][L] tensor: row c of sample b at ptr + b·bs + c·L
+  const float* ptr[WW_MAX_SETS];   // one tensor per operand set (application of the WN); rows of a [B][.][L] tensor: row c of sample
+                                   // b of set s at ptr[s] + b·bs + c·L
   long long bs;         // batch stride (floats)
   long long mul_off;    // product operand: the partner row lives mul_off floats further (t·s halves); 0 = none
   int rows, shift;      // rows of this segment; time shift of the row's samples (x[k][t] = row[t + shift])
@@ -56,7 +58,9 @@ struct WwParams {
   int n_dy, n_x, M, K, K_main, n_extra;
   int xr;               // staged k-rows per group = 32·2·KT
   int mul;              // 1: every k-row is staged twice (row and partner) and multiplied when its fragment is read
-  int n_groups, ksplit, B, L, tiles_per_seq, n_tiles;
+  int n_groups, ksplit, B, L, tiles_per_seq, n_tiles;   // n_tiles: per operand set
+  int n_sets;           // operand sets whose gradients are SUMMED (the applications of one WN in a train step share their weights:
+                        // one launch, one set of slabs and one reduction for all of them); workgroup x works on set x % n_sets
   int RX;               // staged rows of a k-row slot: xr·(1 + mul) (+ 8 for the leftover rows), a multiple of 8
   int misaligned;       // some tap shift is not a multiple of 4 samples (|shift| < 4): straddling pieces are patched in LDS
   int exp;              // diagnostics (FST_WW_EXP, timing only, wrong results): 1 every LDS-DMA piece from the zero block, 2 no k-step
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_s >> 1, wk = wave_s & 1;          // 4 (output-row pairs) × 2 (k-row halves of the group)
   const int g = blockIdx.y, L = p.L;
+  const int set = blockIdx.x % p.n_sets;                  // this workgroup's operand set (wave-uniform)
   const int dslot_bytes = WW_MROWS * 128, xslot_bytes = p.RX * 128;
   char* const xring = ww_lds + WW_ND * dslot_bytes;
   const char* const zero16 = reinterpret_cast<const char*>(ww_zero16);
@@ -170,9 +175,9 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
     dsrc[k].p = nullptr; dsrc[k].bs = 0; dsrc[k].t = 4 * q;
     if (r < p.M) {
       if (p.n_dy > 1 && r >= p.dy[0].rows) {
-        dsrc[k].p = p.dy[1].ptr + ((long long)(r - p.dy[0].rows) * L + 4 * q); dsrc[k].bs = (int)p.dy[1].bs;
+        dsrc[k].p = p.dy[1].ptr[set] + ((long long)(r - p.dy[0].rows) * L + 4 * q); dsrc[k].bs = (int)p.dy[1].bs;
       } else {
-        dsrc[k].p = p.dy[0].ptr + ((long long)r * L + 4 * q); dsrc[k].bs = (int)p.dy[0].bs;
+        dsrc[k].p = p.dy[0].ptr[set] + ((long long)r * L + 4 * q); dsrc[k].bs = (int)p.dy[0].bs;
       }
     }
   }
@@ -201,12 +206,12 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
       for (int j = 0; j < 3; ++j)
         if (si + 1 < p.n_x && c0 >= p.x[si].rows) { c0 -= p.x[si].rows; ++si; }
       // the segment's fields by a chain of compares (kernel arguments are read with scalar loads; no pointer into the argument block)
-      const float* sp = p.x[0].ptr;
+      const float* sp = p.x[0].ptr[set];
       long long sbs = p.x[0].bs, smo = p.x[0].mul_off;
       int ssh = p.x[0].shift;
-      if (si == 1) { sp = p.x[1].ptr; sbs = p.x[1].bs; smo = p.x[1].mul_off; ssh = p.x[1].shift; }
-      if (si == 2) { sp = p.x[2].ptr; sbs = p.x[2].bs; smo = p.x[2].mul_off; ssh = p.x[2].shift; }
-      if (si == 3) { sp = p.x[3].ptr; sbs = p.x[3].bs; smo = p.x[3].mul_off; ssh = p.x[3].shift; }
+      if (si == 1) { sp = p.x[1].ptr[set]; sbs = p.x[1].bs; smo = p.x[1].mul_off; ssh = p.x[1].shift; }
+      if (si == 2) { sp = p.x[2].ptr[set]; sbs = p.x[2].bs; smo = p.x[2].mul_off; ssh = p.x[2].shift; }
+      if (si == 3) { sp = p.x[3].ptr[set]; sbs = p.x[3].bs; smo = p.x[3].mul_off; ssh = p.x[3].shift; }
       xsrc[k].p = sp + ((long long)c0 * L + ssh + 4 * q) + (partner ? smo : 0);
       xsrc[k].bs = (int)sbs;
       xsrc[k].t = ssh + 4 * q;
@@ -269,8 +274,10 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float ev[2] = {0.f, 0.f};                                // leftover k-row: partial dot products of this thread's two dy units
 
-  const int tile_begin = (int)(((long long)blockIdx.x * p.n_tiles) / p.ksplit);
-  const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.n_tiles) / p.ksplit);
+  // the workgroups x ≡ set (mod n_sets) share the set's tiles
+  const int wg_in_set = blockIdx.x / p.n_sets, wgs_of_set = (p.ksplit - set + p.n_sets - 1) / p.n_sets;
+  const int tile_begin = (int)(((long long)wg_in_set * p.n_tiles) / wgs_of_set);
+  const int tile_end = (int)(((long long)(wg_in_set + 1) * p.n_tiles) / wgs_of_set);
   const int m_blocks = (p.M + 31) >> 5;
   const int k_blocks_here = min(2 * KT, ((p.K_main + 31) >> 5) - g * 2 * KT);   // live k-row blocks of this group
   const bool do_extra = NE > 0 && g == 0;
@@ -464,18 +471,14 @@ __device__ __forceinline__ void ww_scatter(const WwParams& p, int m, int kk, flo
   w[(long long)m * sm + (long long)c * sc + off] = v;
 }
 
-__global__ __launch_bounds__(1024) void wn_wgrad_reduce_kernel(WwParams p) {
-  // 1024 threads = 256 quads of 4 consecutive slab floats (4 KiB contiguous per slab: the [m][Kcols] rows follow each other) x 4
-  // slab groups; eight 16-byte loads in flight per thread
-  __shared__ float4 part[3][256];
-  const int cx = threadIdx.x & 255, sg = threadIdx.x >> 8;
-  const long long e0 = ((long long)blockIdx.x * 256 + cx) * 4;          // first of this thread's 4 floats in the [M][Kcols] plane
-  const long long plane = (long long)p.M * p.Kcols;
-  const bool live = e0 < plane;
+__global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(WwParams p) {
+  __shared__ float4 part[4][64];
+  const int m = blockIdx.y, cx = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int kk0 = blockIdx.x * 256 + cx * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) {
+  if (kk0 < p.Kcols) {
     const long long st = (long long)WW_MROWS * p.Kcols;
-    const float* q = p.slab + e0;
+    const float* q = p.slab + (long long)m * p.Kcols + kk0;
     int sl = sg;
     for (; sl + 28 < p.ksplit; sl += 32) {
       float4 v[8];
@@ -489,26 +492,23 @@ __global__ __launch_bounds__(1024) void wn_wgrad_reduce_kernel(WwParams p) {
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   }
-  if (sg > 0) part[sg - 1][cx] = s;
+  part[sg][cx] = s;
   __syncthreads();
-  if (sg == 0 && live) {
+  if (sg == 0 && kk0 < p.Kcols) {
+    float4 t = part[0][cx];
 #pragma unroll
-    for (int g2 = 0; g2 < 3; ++g2) { const float4 o = part[g2][cx]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
-    const int m = (int)(e0 / p.Kcols), kk0 = (int)(e0 - (long long)m * p.Kcols);
-    const float tv[4] = {s.x, s.y, s.z, s.w};
+    for (int g2 = 1; g2 < 4; ++g2) { const float4 o = part[g2][cx]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (kk0 + j < p.K_main) ww_scatter(p, m, kk0 + j, tv[j]);
   }
-  // the leftover k-row (VALU sums): slab group 1 of the first workgroups takes it, one output row per thread
-  if (sg == 1 && p.n_extra > 0) {
-    const int m = blockIdx.x * 256 + cx;
-    if (m < p.M) {
-      const float* q = p.slab_extra + (long long)m * 2;
-      float e = 0.f;
-      for (int sl = 0; sl < p.ksplit; ++sl) e += q[(long long)sl * WW_MROWS * 2];
-      ww_scatter(p, m, p.K_main, e);
-    }
+  // the leftover k-rows (VALU sums): the last column block's idle slab-group-1 threads take them
+  if (blockIdx.x == gridDim.x - 1 && sg == 1 && cx < p.n_extra && p.K_main < p.K) {
+    const float* q = p.slab_extra + (long long)m * 2 + cx;
+    float e = 0.f;
+    for (int sl = 0; sl < p.ksplit; ++sl) e += q[(long long)sl * WW_MROWS * 2];
+    ww_scatter(p, m, p.K_main + cx, e);
   }
 }
 
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(1024) void wn_wgrad_reduce_kernel(WwParams p) {
 static inline bool ww_al16(const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // geometry shared by the size query and the launchers; kind 0 = in_layer + cond_layer, 1 = res_skip
-static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams* p) {
+static int ww_geometry(int kind, int B, int L, int n, int h, int last, int n_sets, WwParams* p) {
   const int KT = kind == 0 ? 3 : 2;
   p->M = kind == 0 ? 2 * n : (last ? n : 2 * n);
   p->K = kind == 0 ? 3 * n + h : n;
@@ -534,9 +534,10 @@ static int ww_geometry(int kind, int B, int L, int n, int h, int last, WwParams*
   p->n_tiles = B * p->tiles_per_seq;
   const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
   int ks = cus / p->n_groups;
-  if (ks < 1) ks = 1;
-  if (ks > p->n_tiles) ks = p->n_tiles;
+  if (ks > p->n_tiles * n_sets) ks = p->n_tiles * n_sets;
+  if (ks < n_sets) ks = n_sets;                                    // every operand set has a workgroup of its own
   p->ksplit = ks;
+  p->n_sets = n_sets;
   return KT;
 }
 
@@ -554,7 +555,7 @@ extern "C" int fst_wn_wgrad_ok(int kind, int B, int L, int n, int h, int dil) {
 extern "C" int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, int h, int last) {
   if (!fst_wn_wgrad_ok(kind, B, L, n, h, 4)) return -1;                        // (the workspace does not depend on the dilation)
   WwParams p;
-  ww_geometry(kind, B, L, n, h, last, &p);
+  ww_geometry(kind, B, L, n, h, last, WW_MAX_SETS, &p);                        // (nor — above n_sets workgroups — on the set count)
   return (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2);
 }
 
@@ -574,31 +575,38 @@ static int ww_launch(WwParams& p, int KT, void* stream) {
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_wn_wgrad")) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
-  const long long quads = ((long long)p.M * p.Kcols + 3) / 4;
-  hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(1024), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3((unsigned)((p.Kcols + 255) / 256), (unsigned)p.M), dim3(256), 0, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0, int64_t u0_bs, float* dw_in, float* dw_cond,
-                               float* workspace, int64_t workspace_floats, int B, int L, int n, int h, int dil, int a_slack,
-                               int64_t numel_a, void* stream) {
+extern "C" int fst_wn_wgrad_in(const float* const* dg, const float* const* a, const float* const* u0, int n_sets, int64_t u0_bs,
+                               float* dw_in, float* dw_cond, float* workspace, int64_t workspace_floats, int B, int L, int n, int h,
+                               int dil, int a_slack, int64_t numel_a, void* stream) {
   FST_REQUIRE(dg && a && u0 && dw_in && dw_cond && workspace, "fst_wn_wgrad_in: null operand");
+  FST_REQUIRE(n_sets >= 1 && n_sets <= WW_MAX_SETS, "fst_wn_wgrad_in: %d operand sets (1..%d)", n_sets, WW_MAX_SETS);
   const int served = fst_wn_wgrad_ok(0, B, L, n, h, dil);
   FST_REQUIRE(served == 1 || (served == 2 && a_slack), "fst_wn_wgrad_in: unsupported shape B=%d L=%d n=%d h=%d dil=%d (needs L %% 32 == 0, "
               "n < 128, h <= 32, and dil %% 4 == 0 or — with 16 readable bytes either side of a — dil < 4)", B, L, n, h, dil);
   FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_in: B*n*L does not match the element count %lld of a", (long long)numel_a);
   FST_REQUIRE(B == 1 || u0_bs >= (int64_t)h * L, "fst_wn_wgrad_in: u0 batch stride %lld < h*L", (long long)u0_bs);
-  FST_REQUIRE(u0_bs % 4 == 0 && ww_al16(dg) && ww_al16(a) && ww_al16(u0) && ww_al16(workspace), "fst_wn_wgrad_in: operands must be 16-byte aligned");
+  FST_REQUIRE(u0_bs % 4 == 0 && ww_al16(workspace), "fst_wn_wgrad_in: operands must be 16-byte aligned");
   WwParams p = {};
-  const int KT = ww_geometry(0, B, L, n, h, 0, &p);
+  const int KT = ww_geometry(0, B, L, n, h, 0, n_sets, &p);
   FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2), "fst_wn_wgrad_in: workspace of %lld floats is too small",
               (long long)workspace_floats);
   p.n_dy = 1;
-  p.dy[0] = {dg, (long long)2 * n * L, 0, 2 * n, 0, 0, 0, 0, 0};
+  p.dy[0] = {{}, (long long)2 * n * L, 0, 2 * n, 0, 0, 0, 0, 0};
   p.n_x = 4;
-  for (int tap = 0; tap < 3; ++tap) p.x[tap] = {a, (long long)n * L, 0, n, (tap - 1) * dil, 0, tap, 3, 3 * n};
-  p.x[3] = {u0, (long long)u0_bs, 0, h, 0, 1, 0, 1, h};
+  for (int tap = 0; tap < 3; ++tap) p.x[tap] = {{}, (long long)n * L, 0, n, (tap - 1) * dil, 0, tap, 3, 3 * n};
+  p.x[3] = {{}, (long long)u0_bs, 0, h, 0, 1, 0, 1, h};
+  for (int s = 0; s < n_sets; ++s) {
+    FST_REQUIRE(dg[s] && a[s] && u0[s], "fst_wn_wgrad_in: null operand in set %d", s);
+    FST_REQUIRE(ww_al16(dg[s]) && ww_al16(a[s]) && ww_al16(u0[s]), "fst_wn_wgrad_in: operands must be 16-byte aligned");
+    p.dy[0].ptr[s] = dg[s];
+    for (int tap = 0; tap < 3; ++tap) p.x[tap].ptr[s] = a[s];
+    p.x[3].ptr[s] = u0[s];
+  }
   p.misaligned = dil % 4 != 0;
   p.slab = workspace;
   p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
@@ -606,26 +614,30 @@ extern "C" int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0,
   return ww_launch(p, KT, stream);
 }
 
-extern "C" int fst_wn_wgrad_rs(const float* d_a, const float* d_out, const float* ts, float* dw_rs, float* workspace,
-                               int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a, void* stream) {
+extern "C" int fst_wn_wgrad_rs(const float* const* d_a, const float* const* d_out, const float* const* ts, int n_sets, float* dw_rs,
+                               float* workspace, int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a,
+                               void* stream) {
   FST_REQUIRE(d_out && ts && dw_rs && workspace && (last || d_a), "fst_wn_wgrad_rs: null operand");
+  FST_REQUIRE(n_sets >= 1 && n_sets <= WW_MAX_SETS, "fst_wn_wgrad_rs: %d operand sets (1..%d)", n_sets, WW_MAX_SETS);
   FST_REQUIRE(fst_wn_wgrad_ok(1, B, L, n, 0, 4), "fst_wn_wgrad_rs: unsupported shape B=%d L=%d n=%d (needs L %% 32 == 0, n < 128)", B, L, n);
   FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_wgrad_rs: B*n*L does not match the element count %lld", (long long)numel_a);
-  FST_REQUIRE(ww_al16(d_a) && ww_al16(d_out) && ww_al16(ts) && ww_al16(workspace), "fst_wn_wgrad_rs: operands must be 16-byte aligned");
+  FST_REQUIRE(ww_al16(workspace), "fst_wn_wgrad_rs: operands must be 16-byte aligned");
   WwParams p = {};
-  const int KT = ww_geometry(1, B, L, n, 0, last, &p);
+  const int KT = ww_geometry(1, B, L, n, 0, last, n_sets, &p);
   FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2), "fst_wn_wgrad_rs: workspace of %lld floats is too small",
               (long long)workspace_floats);
-  if (last) {
-    p.n_dy = 1;
-    p.dy[0] = {d_out, (long long)n * L, 0, n, 0, 0, 0, 0, 0};
-  } else {
-    p.n_dy = 2;
-    p.dy[0] = {d_a, (long long)n * L, 0, n, 0, 0, 0, 0, 0};
-    p.dy[1] = {d_out, (long long)n * L, 0, n, 0, 0, 0, 0, 0};
-  }
+  p.n_dy = last ? 1 : 2;
+  p.dy[0] = {{}, (long long)n * L, 0, n, 0, 0, 0, 0, 0};
+  p.dy[1] = {{}, (long long)n * L, 0, n, 0, 0, 0, 0, 0};
   p.n_x = 1;
-  p.x[0] = {ts, (long long)2 * n * L, (long long)n * L, n, 0, 0, 0, 1, n};   // t rows; the s rows n·L floats further
+  p.x[0] = {{}, (long long)2 * n * L, (long long)n * L, n, 0, 0, 0, 1, n};   // t rows; the s rows n·L floats further
+  for (int s = 0; s < n_sets; ++s) {
+    FST_REQUIRE(d_out[s] && ts[s] && (last || d_a[s]), "fst_wn_wgrad_rs: null operand in set %d", s);
+    FST_REQUIRE(ww_al16(d_out[s]) && ww_al16(ts[s]) && (last || ww_al16(d_a[s])), "fst_wn_wgrad_rs: operands must be 16-byte aligned");
+    if (last) p.dy[0].ptr[s] = d_out[s];
+    else { p.dy[0].ptr[s] = d_a[s]; p.dy[1].ptr[s] = d_out[s]; }
+    p.x[0].ptr[s] = ts[s];
+  }
   p.slab = workspace;
   p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
   p.w[0] = dw_rs; p.w[1] = nullptr;

@@ -736,43 +736,132 @@ def has_slack(t: Tensor) -> bool:
     return t.is_contiguous() and off >= 4 and t.untyped_storage().nbytes() >= (off + t.numel() + 4) * 4
 
 
-def wn_wgrad_in(dg: Tensor, a: Tensor, u0: Tensor, dw_in: Tensor, dw_cond: Tensor, n: int, h: int, dil: int) -> None:
-    """dw_in [2n, n, 3] = Σ dg ⊗ a(t + (τ−1)·dil),  dw_cond [2n, h, 1] = Σ dg ⊗ u0 — written in place (fst_wn_wgrad_in)."""
+WN_WGRAD_MAX_SETS = 3        # (WW_MAX_SETS of csrc/wn_wgrad.hip)
+
+
+def _sets(x) -> list:
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def wn_wgrad_in(dg, a, u0, dw_in: Tensor, dw_cond: Tensor, n: int, h: int, dil: int) -> None:
+    """dw_in [2n, n, 3] = Σ dg ⊗ a(t + (τ−1)·dil),  dw_cond [2n, h, 1] = Σ dg ⊗ u0 — written in place (fst_wn_wgrad_in).
+    ``dg``, ``a``, ``u0``: one tensor each, or equally long lists of up to 3 same-shaped operand sets whose gradients are summed
+    by the one launch (the applications of a WN in a train step)."""
     lib = _lib.load()
-    B, _, L = dg.shape
-    u0_bs, _ = _ncl(u0, "u0")
-    numel = _same_numel(a)
-    if dg.numel() != 2 * numel or not dg.is_contiguous() or tuple(a.shape) != (B, n, L) or tuple(u0.shape) != (B, h, L):
-        raise ValueError("wn_wgrad_in: dg must be contiguous [B, 2n, L], a [B, n, L], u0 [B, h, L]")
+    dgs, as_, u0s = _sets(dg), _sets(a), _sets(u0)
+    if not (1 <= len(dgs) <= WN_WGRAD_MAX_SETS and len(as_) == len(dgs) and len(u0s) == len(dgs)):
+        raise ValueError(f"wn_wgrad_in: {len(dgs)}/{len(as_)}/{len(u0s)} operand sets (1..{WN_WGRAD_MAX_SETS}, equally many)")
+    B, _, L = dgs[0].shape
+    u0_bs, _ = _ncl(u0s[0], "u0")
+    numel = _same_numel(*as_)
+    slack = True
+    for dg_s, a_s, u0_s in zip(dgs, as_, u0s):
+        if dg_s.numel() != 2 * numel or not dg_s.is_contiguous() or tuple(a_s.shape) != (B, n, L) or tuple(u0_s.shape) != (B, h, L):
+            raise ValueError("wn_wgrad_in: dg must be contiguous [B, 2n, L], a [B, n, L], u0 [B, h, L]")
+        if _ncl(u0_s, "u0")[0] != u0_bs:
+            raise ValueError("wn_wgrad_in: the operand sets' u0 tensors must share one batch stride")
+        slack = slack and has_slack(a_s)
     for t, sh in ((dw_in, (2 * n, n, 3)), (dw_cond, (2 * n, h, 1))):
         if tuple(t.shape) != sh or not t.is_contiguous() or t.dtype != torch.float32:
             raise ValueError(f"wn_wgrad_in: gradient target of shape {tuple(t.shape)}, expected contiguous {sh}")
     ws_n = lib.fst_wn_wgrad_workspace_floats(0, B, L, n, h, 0)
-    ws = torch.empty(ws_n, device=dg.device, dtype=torch.float32)
+    ws = torch.empty(ws_n, device=dgs[0].device, dtype=torch.float32)
+    ns = len(dgs)
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
-    check(lib.fst_wn_wgrad_in(ptr(dg), ptr(a), ptr(u0), u0_bs, ptr(dw_in), ptr(dw_cond), ptr(ws), ws_n, B, L, n, h, dil,
-                              int(has_slack(a)), numel, stream_ptr()), "fst_wn_wgrad_in")
+    check(lib.fst_wn_wgrad_in(_ptr_sets(dgs), _ptr_sets(as_), _ptr_sets(u0s), ns, u0_bs, ptr(dw_in), ptr(dw_cond), ptr(ws), ws_n, B, L,
+                              n, h, dil, int(slack), numel, stream_ptr()), "fst_wn_wgrad_in")
     if t0 is not None:
-        KERNEL_TIMER.end("wn_wgrad_kernel<2, 3>", t0, 2.0 * B * L * 2 * n * (3 * n + h), 4.0 * B * L * (2 * n + n + h))
+        KERNEL_TIMER.end("wn_wgrad_kernel<2, 3> bf3", t0, 2.0 * ns * B * L * 2 * n * (3 * n + h), 4.0 * ns * B * L * (2 * n + n + h))
 
 
-def wn_wgrad_rs(d_a: Optional[Tensor], d_out: Tensor, ts: Tensor, dw_rs: Tensor, last: bool, n: int) -> None:
-    """dw_rs [2n | n, n, 1] = Σ [d_a ; d_out] ⊗ (t·s), acts = t·s re-formed from the saved gate halves ts [B, 2n, L] (fst_wn_wgrad_rs)."""
+def wn_wgrad_rs(d_a, d_out, ts, dw_rs: Tensor, last: bool, n: int) -> None:
+    """dw_rs [2n | n, n, 1] = Σ [d_a ; d_out] ⊗ (t·s), acts = t·s re-formed from the saved gate halves ts [B, 2n, L] (fst_wn_wgrad_rs).
+    One tensor each or lists of up to 3 operand sets, as ``wn_wgrad_in``; ``d_a`` is None exactly on the last layer."""
     lib = _lib.load()
-    B, _, L = d_out.shape
-    numel = _same_numel(d_out, d_a)
+    d_outs, tss = _sets(d_out), _sets(ts)
+    d_as = [None] * len(d_outs) if d_a is None else _sets(d_a)
+    if not (1 <= len(d_outs) <= WN_WGRAD_MAX_SETS and len(tss) == len(d_outs) and len(d_as) == len(d_outs)):
+        raise ValueError(f"wn_wgrad_rs: {len(d_as)}/{len(d_outs)}/{len(tss)} operand sets (1..{WN_WGRAD_MAX_SETS}, equally many)")
+    B, _, L = d_outs[0].shape
+    numel = _same_numel(*d_outs, *[t for t in d_as if t is not None])
     M = n if last else 2 * n
-    if ts.numel() != 2 * numel or not ts.is_contiguous() or (d_a is None) != bool(last):
-        raise ValueError("wn_wgrad_rs: ts must be contiguous [B, 2n, L]; d_a is None exactly on the last layer")
+    for da_s, ts_s in zip(d_as, tss):
+        if ts_s.numel() != 2 * numel or not ts_s.is_contiguous() or (da_s is None) != bool(last):
+            raise ValueError("wn_wgrad_rs: ts must be contiguous [B, 2n, L]; d_a is None exactly on the last layer")
     if tuple(dw_rs.shape) != (M, n, 1) or not dw_rs.is_contiguous() or dw_rs.dtype != torch.float32:
         raise ValueError(f"wn_wgrad_rs: gradient target of shape {tuple(dw_rs.shape)}, expected contiguous {(M, n, 1)}")
     ws_n = lib.fst_wn_wgrad_workspace_floats(1, B, L, n, 0, int(last))
-    ws = torch.empty(ws_n, device=d_out.device, dtype=torch.float32)
+    ws = torch.empty(ws_n, device=d_outs[0].device, dtype=torch.float32)
+    ns = len(d_outs)
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
-    check(lib.fst_wn_wgrad_rs(ptr(d_a), ptr(d_out), ptr(ts), ptr(dw_rs), ptr(ws), ws_n, int(last), B, L, n, numel, stream_ptr()),
-          "fst_wn_wgrad_rs")
+    check(lib.fst_wn_wgrad_rs(None if last else _ptr_sets(d_as), _ptr_sets(d_outs), _ptr_sets(tss), ns, ptr(dw_rs), ptr(ws), ws_n,
+                              int(last), B, L, n, numel, stream_ptr()), "fst_wn_wgrad_rs")
     if t0 is not None:
-        KERNEL_TIMER.end("wn_wgrad_kernel<2, 2>", t0, 2.0 * B * L * M * n, 4.0 * B * L * (M + 2 * n))
+        KERNEL_TIMER.end("wn_wgrad_kernel<2, 2> bf3", t0, 2.0 * ns * B * L * M * n, 4.0 * ns * B * L * (M + 2 * n))
+
+
+def _ptr_sets(ts: Sequence[Tensor]):
+    """Host array of the operand sets' device addresses (a ``const float* const*`` argument)."""
+    arr = (ctypes.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise ValueError("operand sets must be fp32 device tensors")
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class WNGradPool:
+    """Weight-gradient operands of the applications of ONE WN whose weights go through ``WGradJoinFn``: every application's
+    backward leaves (dg, a, u0) / (d_a, d_out, ts) of each layer here instead of launching its own weight-gradient kernels; the
+    join node's backward — which autograd runs after ALL applications that take part in the pass — sums them with one launch per
+    layer and kind."""
+
+    def __init__(self):
+        self.pending: dict = {}
+
+    def add(self, key, operands) -> None:
+        self.pending.setdefault(key, []).append(operands)
+
+
+class WGradJoinFn(torch.autograd.Function):
+    """Identity on the flat weight tensor of a WN; backward adds the deferred in_layer / cond_layer / res_skip weight gradients
+    of every application recorded in ``pool`` to the (autograd-summed) gradient of the flat tensor.  The applications zero those
+    segments of the gradients they return, so the summed segments are written, not accumulated."""
+
+    @staticmethod
+    def forward(ctx, pool: WNGradPool, specs: "WNSpecs", flat: Tensor):
+        ctx.pool, ctx.specs = pool, specs
+        return flat.view_as(flat)
+
+    @staticmethod
+    def backward(ctx, g):
+        S, pool = ctx.specs, ctx.pool
+        pending, pool.pending = pool.pending, {}
+        if not pending:
+            return None, None, g
+        g = g.contiguous()
+        nl, n, h = S.n_layers, S.n, S.h
+        dw = S.unflatten(g)
+        g_cond_w, g_in_w, g_rs_w = dw[2], dw[6: 6 + nl], dw[6 + 2 * nl: 6 + 3 * nl]
+        for (kind, i), sets in pending.items():
+            for c0 in range(0, len(sets), WN_WGRAD_MAX_SETS):
+                chunk = sets[c0: c0 + WN_WGRAD_MAX_SETS]
+                cols = [list(col) for col in zip(*chunk)]
+                if kind == 0:
+                    t_in, t_cond = g_in_w[i], g_cond_w[2 * n * i: 2 * n * (i + 1)]
+                    if c0:
+                        t_in, t_cond = torch.empty_like(t_in), torch.empty_like(t_cond)
+                    wn_wgrad_in(cols[0], cols[1], cols[2], t_in, t_cond, n, h, 2 ** i)
+                    if c0:
+                        g_in_w[i].add_(t_in)
+                        g_cond_w[2 * n * i: 2 * n * (i + 1)].add_(t_cond)
+                else:
+                    last = i == nl - 1
+                    t_rs = torch.empty_like(g_rs_w[i]) if c0 else g_rs_w[i]
+                    wn_wgrad_rs(None if last else cols[0], cols[1], cols[2], t_rs, last, n)
+                    if c0:
+                        g_rs_w[i].add_(t_rs)
+        return None, None, g
 
 
 class WNFoldPlan:
@@ -1086,9 +1175,11 @@ def _wn_forward(specs: WNSpecs, u0: Tensor, flat: Tensor):
     return o, fused, (u0, out, *a_list, *ts_list, *acts_list, flat)
 
 
-def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: bool):
+def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: bool, pool: Optional["WNGradPool"] = None):
     """Backward of the WN stack: the input gradient is ACCUMULATED into ``d_u0`` ([B, h, L], possibly a channel-slice view of
-    a wider tensor with an explicit batch stride); returns the flat weight gradient (None unless ``need_w``)."""
+    a wider tensor with an explicit batch stride); returns the flat weight gradient (None unless ``need_w``).
+    ``pool``: the in_layer / cond_layer / res_skip weight gradients served by the time-as-k kernels are not computed here — their
+    operands are left in the pool and their segments of the returned gradient are zero (``WGradJoinFn`` fills them)."""
     lib = _lib.load()
     nl, h, n = S.n_layers, S.h, S.n
     u0, out = sv[0], sv[1]
@@ -1099,15 +1190,24 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
     in_w, rs_w = weights[6: 6 + nl], weights[6 + 2 * nl: 6 + 3 * nl]
     # every gradient is written into its segment of one flat tensor; every segment is written in full (all WN convs have
     # dense plans, the bias sums are stored, not accumulated), so the tensor needs no zero fill
-    d_flat = torch.empty_like(flat) if need_w else None
+    B, _, L = u0.shape
+    defer_in = [bool(need_w and pool is not None and fused and wn_wgrad_ok(0, B, L, n, h, 2 ** i, a_list[i])) for i in range(nl)]
+    defer_rs = [bool(need_w and pool is not None and fused and wn_wgrad_ok(1, B, L, n, h, 2 ** i)) for i in range(nl)]
+    deferring = any(defer_in) or any(defer_rs)
+    d_flat = (torch.zeros_like(flat) if deferring else torch.empty_like(flat)) if need_w else None
     if need_w and os.environ.get("FST_DEBUG_POISON") == "1":          # tests: an unwritten element shows up as NaN
         d_flat.fill_(float("nan"))
+        for i in range(nl):
+            if defer_in[i]:
+                S.unflatten(d_flat)[6 + i].zero_()
+                S.unflatten(d_flat)[2][2 * n * i: 2 * n * (i + 1)].zero_()
+            if defer_rs[i]:
+                S.unflatten(d_flat)[6 + 2 * nl + i].zero_()
     dw = S.unflatten(d_flat) if need_w else [None] * len(S.shapes)
     g_start_w, g_start_b, g_cond_w, g_cond_b, g_end_w, g_end_b = dw[:6]
     g_in_w, g_in_b = dw[6: 6 + nl], dw[6 + nl: 6 + 2 * nl]
     g_rs_w, g_rs_b = dw[6 + 2 * nl: 6 + 3 * nl], dw[6 + 3 * nl: 6 + 4 * nl]
     do = do.contiguous()
-    B, _, L = u0.shape
     dev = u0.device
 
     d_out = S.end.grad_x0(do, end_w)
@@ -1154,7 +1254,9 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
             mul = n * L if fused else 0
             if fused and os.environ.get("FST_WN_PROD", "1") == "0":                   # diagnostics: materialise acts
                 x_rs, mul = (ts_list[i][:, :n] * ts_list[i][:, n:]).contiguous(), 0
-            if fused and mul and wn_wgrad_ok(1, B, L, n, h, 2 ** i):
+            if defer_rs[i] and mul:
+                pool.add((1, i), (None if last else d_a, d_out, ts_list[i]))
+            elif fused and mul and wn_wgrad_ok(1, B, L, n, h, 2 ** i):
                 wn_wgrad_rs(None if last else d_a, d_out, ts_list[i], g_rs_w[i], last, n)
             elif last:
                 S.rs[i].grad_w(x_rs, None, d_out, x0_mul_off=mul, out0=g_rs_w[i])      # (its bias gradient is d_out_sum, in place)
@@ -1173,7 +1275,9 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
                                    stream_ptr()), "fst_gate_bwd")
         if need_w:
             # in_layer weights and the layer's rows of the stacked cond_layer weights, unpacked in place
-            if fused and wn_wgrad_ok(0, B, L, n, h, 2 ** i, a_list[i]):
+            if defer_in[i]:
+                pool.add((0, i), (dg, a_list[i], u0))
+            elif fused and wn_wgrad_ok(0, B, L, n, h, 2 ** i, a_list[i]):
                 wn_wgrad_in(dg, a_list[i], u0, g_in_w[i], g_cond_w[2 * n * i: 2 * n * (i + 1)], n, h, 2 ** i)
             else:
                 S.ins[i].grad_w(a_list[i], u0, dg, out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])
@@ -1295,8 +1399,9 @@ class FlowFn(torch.autograd.Function):
     channels in place (the data-gradient launches take a batch stride)."""
 
     @staticmethod
-    def forward(ctx, specs: WNSpecs, x: Tensor, flat: Tensor, inverse: bool):
+    def forward(ctx, specs: WNSpecs, x: Tensor, flat: Tensor, inverse: bool, pool: Optional[WNGradPool] = None):
         lib = _lib.load()
+        ctx.pool = pool
         x = x.contiguous()
         h = specs.h
         assert x.size(1) == 2 * h
@@ -1335,8 +1440,8 @@ class FlowFn(torch.autograd.Function):
         if d_o_ext is not None:                                   # someone differentiated the returned WN output itself
             d_o = d_o + d_o_ext
         need_w = ctx.needs_input_grad[2] and _want_weight_grad()
-        d_flat = _wn_backward(S, ctx.fused, sv, d_o, dx[:, : S.h], need_w)     # accumulates into the first h channels of dx
-        return None, (dx if ctx.needs_input_grad[1] else None), d_flat, None
+        d_flat = _wn_backward(S, ctx.fused, sv, d_o, dx[:, : S.h], need_w, ctx.pool)     # accumulates into the first h channels of dx
+        return None, (dx if ctx.needs_input_grad[1] else None), d_flat, None, None
 
 
 class CouplingInvFn(torch.autograd.Function):

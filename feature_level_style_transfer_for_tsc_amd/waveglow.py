@@ -85,15 +85,29 @@ class WN(nn.Module):
         """Effective weights g·v/‖v‖ as ONE flat tensor in ``WNSpecs.shapes`` order.  Inside ``WaveGlow.shared_fold()`` (one
         train step: the weights are the same for the two forward passes and ``infer``) the fold is done once and its
         autograd graph is shared: the three applications' gradients are summed on the flat tensor (two adds per WN)."""
+        return self._folded()[0]
+
+    def _folded(self):
+        """(flat weights, the WNGradPool their gradient is joined through — None outside ``shared_fold`` and on the CPU)."""
         if self._fold_cache is not None and self._fold_cache[0] is not None:
             return self._fold_cache[0]
+        pool = None
         if self.start.weight_v.is_cuda:
             flat = ops.WNFoldFn.apply(self._plan(), *self._fold_inputs())        # one launch (18 weight-norm launches + a cat as torch ops)
+            if self._fold_cache is not None and torch.is_grad_enabled() and flat.requires_grad:
+                # the applications made in this scope leave their weight-gradient operands in the pool; the join node sums them
+                # with one launch per layer (the slab reduction of the time-as-k kernels is paid once, not per application)
+                pool = ops.WNGradPool()
+                flat = ops.WGradJoinFn.apply(pool, self.specs, flat)
         else:
             flat = self.specs.flatten(self._fold())
         if self._fold_cache is not None:
-            self._fold_cache[0] = flat
-        return flat
+            self._fold_cache[0] = (flat, pool)
+        return flat, pool
+
+    def _folded_for(self, inverse: bool):
+        flat, pool = self._folded()
+        return flat, inverse, pool
 
     def _plan(self) -> "ops.WNFoldPlan":
         if self._fold_plan is None:
@@ -170,7 +184,7 @@ class WaveGlow(nn.Module):
             # WN on the first half of the channels + affine coupling as ONE autograd node (ops.FlowFn); Σ log_s of this flow (and
             # Σ z² after the last one) are reduced inside the coupling kernel: WaveGlowLoss picks them up from the attributes below
             # instead of re-reading the tensors (the returned tensors themselves are the reference's)
-            audio, output, s_ls, s_sq = ops.FlowFn.apply(self.WN[k].specs, audio, self.WN[k].folded_weights(), False)
+            audio, output, s_ls, s_sq = ops.FlowFn.apply(self.WN[k].specs, audio, *self.WN[k]._folded_for(False))
             log_s = output[:, n_half:, :]
             log_s._fst_sum = s_ls
             audio._fst_sq_sum = s_sq
@@ -180,7 +194,7 @@ class WaveGlow(nn.Module):
     def infer(self, audio: torch.Tensor, sigma: float = 1.0) -> torch.Tensor:
         n_half = self.n_group // 2
         for k in reversed(range(self.n_flows)):
-            audio = ops.FlowFn.apply(self.WN[k].specs, audio, self.WN[k].folded_weights(), True)[0]
+            audio = ops.FlowFn.apply(self.WN[k].specs, audio, *self.WN[k]._folded_for(True))[0]
             audio = self.convinv[k](audio, reverse=True)
         return audio
 

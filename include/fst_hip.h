@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 7
+#define FST_ABI_VERSION 8
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -266,13 +266,19 @@ int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, 
  * kind 0 = in_layer + cond_layer, 1 = res_skip.  fst_wn_wgrad_ok: 1 when the shape is served (L % 32 == 0, n < 128, h <= 32 and for
  * kind 0 dil % 4 == 0); 2 (kind 0, dil < 4) when it is served provided the caller guarantees 16 readable bytes in front of and
  * behind `a` (a_slack: the 16-byte pieces of a shifted tap start up to 3 samples outside a row); 0: the caller uses fst_conv_wgrad.
- * workspace: fst_wn_wgrad_workspace_floats(...) floats, written. */
+ * Operand SETS: the applications of one WN in a train step (forward on the target batch, forward on the source batch, inverse)
+ * share their weights, so their gradients are summed; dg/a/u0 (d_a/d_out/ts) are HOST arrays of n_sets (1..3) device pointers to
+ * same-shaped operands and one launch sums over all of them — the partial slabs and their reduction, which cost as much as the
+ * products of one set, are paid once instead of n_sets times.
+ * workspace: fst_wn_wgrad_workspace_floats(...) floats, written (independent of n_sets). */
 int fst_wn_wgrad_ok(int kind, int B, int L, int n, int h, int dil);
 int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, int h, int last);
-int fst_wn_wgrad_in(const float* dg, const float* a, const float* u0, int64_t u0_bs, float* dw_in, float* dw_cond, float* workspace,
-                    int64_t workspace_floats, int B, int L, int n, int h, int dil, int a_slack, int64_t numel_a, void* stream);
-int fst_wn_wgrad_rs(const float* d_a /* NULL iff last */, const float* d_out, const float* ts, float* dw_rs, float* workspace,
-                    int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a, void* stream);
+int fst_wn_wgrad_in(const float* const* dg, const float* const* a, const float* const* u0, int n_sets, int64_t u0_bs, float* dw_in,
+                    float* dw_cond, float* workspace, int64_t workspace_floats, int B, int L, int n, int h, int dil, int a_slack,
+                    int64_t numel_a, void* stream);
+int fst_wn_wgrad_rs(const float* const* d_a /* NULL iff last */, const float* const* d_out, const float* const* ts, int n_sets,
+                    float* dw_rs, float* workspace, int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a,
+                    void* stream);
 
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */

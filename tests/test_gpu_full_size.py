@@ -236,3 +236,44 @@ def test_time_as_k_weight_gradient_kernels(n, h, Bq, L, dil):
         ops.wn_wgrad_rs(None if last else d_a, d_out, ts, dw, last, n)
         dy = d_out if last else torch.cat([d_a, d_out], 1)
         assert_close(dw[:, :, 0], torch.einsum("bmt,bct->mc", dy.double(), acts), 1e-4, f"res_skip dW (last={last})")
+
+
+@pytest.mark.parametrize("n,h,Bq,L,dil,n_sets", [(120, 25, 64, 512, 4, 3), (120, 25, 64, 512, 1, 2), (16, 5, 2, 64, 2, 3), (33, 31, 1, 32, 4, 3),
+                                                 (8, 3, 1, 32, 8, 2)])      # (fewer tiles than workgroups per set)
+def test_time_as_k_weight_gradients_summed_over_operand_sets(n, h, Bq, L, dil, n_sets):
+    """One launch for the applications of a WN (fst_wn_wgrad_in / _rs with n_sets operand sets) = the sum of the per-set fp64
+    gradients; bit for bit the same twice."""
+    g = torch.Generator(device=DEV).manual_seed(n + 13 * L + dil + n_sets)
+    a, dgd, u0, ts, d_a, d_out = [], [], [], [], [], []
+    for _ in range(n_sets):
+        t = ops.empty_with_slack(Bq, n, L, DEV)
+        t.untyped_storage().copy_(torch.full((Bq * n * L + 8,), float("nan")).untyped_storage())
+        t.copy_(_rnd(g, Bq, n, L))
+        a.append(t)
+        dgd.append(_rnd(g, Bq, 2 * n, L))
+        u0.append(_rnd(g, Bq, 2 * h, L)[:, :h])
+        ts.append(_rnd(g, Bq, 2 * n, L))
+        d_a.append(_rnd(g, Bq, n, L))
+        d_out.append(_rnd(g, Bq, n, L))
+    dw_in, dw_cond = torch.full((2 * n, n, 3), 7.0, device=DEV), torch.full((2 * n, h, 1), 7.0, device=DEV)
+    ops.wn_wgrad_in(dgd, a, u0, dw_in, dw_cond, n, h, dil)
+    want_in = want_cond = 0
+    for s in range(n_sets):
+        ap = F.pad(a[s].double(), (dil, dil))
+        want_in = want_in + torch.stack([torch.einsum("bmt,bct->mc", dgd[s].double(), ap[:, :, k * dil: k * dil + L]) for k in range(3)], dim=2)
+        want_cond = want_cond + torch.einsum("bmt,bct->mc", dgd[s].double(), u0[s].double())
+    assert_close(dw_in, want_in, 1e-4, "in_layer dW over sets")
+    assert_close(dw_cond[:, :, 0], want_cond, 1e-4, "cond_layer dW over sets")
+    again_in, again_cond = torch.empty_like(dw_in), torch.empty_like(dw_cond)
+    ops.wn_wgrad_in(dgd, a, u0, again_in, again_cond, n, h, dil)
+    assert torch.equal(again_in, dw_in) and torch.equal(again_cond, dw_cond)
+    for last in (False, True):
+        dw = torch.full((n if last else 2 * n, n, 1), 7.0, device=DEV)
+        ops.wn_wgrad_rs(None if last else d_a, d_out, ts, dw, last, n)
+        want = 0
+        for s in range(n_sets):
+            dy = d_out[s] if last else torch.cat([d_a[s], d_out[s]], 1)
+            want = want + torch.einsum("bmt,bct->mc", dy.double(), ts[s][:, :n].double() * ts[s][:, n:].double())
+        assert_close(dw[:, :, 0], want, 1e-4, f"res_skip dW over sets (last={last})")
+    with pytest.raises(ValueError):
+        ops.wn_wgrad_in(dgd * 2, a * 2, u0 * 2, dw_in, dw_cond, n, h, dil)          # 4+ sets: the caller chunks

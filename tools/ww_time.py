@@ -28,7 +28,17 @@ def timed(fn, reps=20):
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
-out = [f"FST_WW_EXP={os.environ.get('FST_WW_EXP', '0')}"]
+NS = int(os.environ.get("SETS", 1))              # operand sets summed by one launch (the applications of a WN)
+if NS > 1:
+    def more(t):
+        out = [t]
+        for _ in range(NS - 1):
+            c = ops.empty_with_slack(*t.shape, dev) if t is a else torch.empty_like(t)
+            out.append(c.copy_(t))
+        return out
+    a, dg, ts, d_a, d_out = more(a), more(dg), more(ts), more(d_a), more(d_out)
+    u0 = [u0] + [rnd(B, 2 * h, L)[:, :h] for _ in range(NS - 1)]
+out = [f"FST_WW_EXP={os.environ.get('FST_WW_EXP', '0')} sets={NS}"]
 for dil in (1, 4, 128):
     out.append(f"in dil={dil}: {timed(lambda: ops.wn_wgrad_in(dg, a, u0, dw_in, dw_cond, n, h, dil)):6.1f} us")
 out.append(f"rs: {timed(lambda: ops.wn_wgrad_rs(d_a, d_out, ts, dw_rs, False, n)):6.1f} us")
