@@ -35,12 +35,11 @@ typedef unsigned wn_u32x4 __attribute__((ext_vector_type(4)));
 #define WN_LDS_VOID(p) ((__attribute__((address_space(3))) void*)(p))
 
 #define WN_TN 128                                  // time samples per workgroup
-#define WN_NBLK (WN_TN / 32 + 1)                   // 32-sample column blocks per 8-channel row group (+1: sub-shift spill)
-#define WN_GS (WN_NBLK * 1024 + 128)               // bytes per 8-channel row group (+128: the lane halves hit different banks)
+// forward kernel, per NW waves: WN_NBLK = NW + 1 32-sample column blocks per 8-channel row group (+1: sub-shift spill), WN_GS =
+// WN_NBLK·1024 + 128 bytes per row group (+128: the lane halves hit different banks), ring slot = WN_A_BYTES + 2·WN_GS
 #define WN_A_BYTES (8 * 2048)                      // 8 row blocks × (1 KiB hi + 1 KiB lo fragments)
-#define WN_SLOT (WN_A_BYTES + 2 * WN_GS)
 #define WN_TILE_BYTES (32 * 36 * 4)                // one wave's [32][36] fp32 transpose tile
-#define WN_LDS_BYTES (3 * WN_SLOT)
+#define WN_FWD_LDS(NW) (3 * (WN_A_BYTES + 2 * (((NW) + 1) * 1024 + 128)))
 
 __device__ __forceinline__ void wn_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
   const wn_f32x2 v = {a, b};
@@ -337,10 +336,15 @@ __device__ __forceinline__ void wn_tile_row_sums(const float* tile, float* rows,
   }
 }
 
-__global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
+// NW waves per workgroup = 32·NW time samples: every wave streams the whole weight image through LDS whatever the tile width, so
+// the L2→LDS fill per sample — the limiter of the 4-wave form (830 MB of pieces per launch) — halves at NW = 8
+// (one workgroup of 8 waves per CU instead of two of 4: the same 2 waves per SIMD).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(WnFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int F_TN = 32 * NW, F_NBLK = F_TN / 32 + 1, F_GS = F_NBLK * 1024 + 128, F_SLOT = WN_A_BYTES + 2 * F_GS;
   constexpr int NA = WN_A_BYTES / 1024;              // 16 one-KiB pieces of A per stage
-  constexpr int NI1 = NA + 2 * WN_NBLK;              // 26 LDS-DMA wave-instructions per GEMM-1 stage
+  constexpr int NI1 = NA + 2 * F_NBLK;              // 26 (NW = 4) / 34 (NW = 8) LDS-DMA wave-instructions per GEMM-1 stage
   char* const ldsb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
   const int half = lane >> 5, l31 = lane & 31;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   int wg = blockIdx.x;
   if ((p.n_wg & 7) == 0) wg = (wg & 7) * (p.n_wg >> 3) + (wg >> 3);
   const int b = wg / p.tiles_per_seq;
-  const int t0 = (wg - b * p.tiles_per_seq) * WN_TN;
+  const int t0 = (wg - b * p.tiles_per_seq) * F_TN;
   const int wave_n0 = wave_s * 32;
   const int L = p.L, n = p.n, h = p.h, CH = p.CH;
   const int S1 = 3 * CH + p.CH2;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   };
   auto stage_src = [&](int k, int slot) {
     StageSrc ss;
-    ss.sl = ldsb + slot * WN_SLOT;
+    ss.sl = ldsb + slot * F_SLOT;
     ss.asrc = p.img + (long long)k * WN_A_BYTES;
     ss.gemm2 = k >= S1;
     ss.a0 = p.last ? 8 : 0;                            // last layer: only the skip-row blocks of GEMM 2 exist
@@ -399,30 +403,31 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   };
   auto issue_piece = [&](const StageSrc& ss, int i) {
     if (ss.gemm2) {
-      const int idx = ss.a0 + wave_s + 4 * i;
-      if (i < 4 && idx < NA)
+      const int idx = ss.a0 + wave_s + NW * i;
+      if (i < 16 / NW && idx < NA)
         __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((WN_EXP & 4) ? zero16 : ss.asrc + idx * 1024 + lane * 16),
                                          WN_LDS_VOID(ss.sl + idx * 1024), 16, 0, 0);
       return;
     }
-    const int idx = wave_s + 4 * i;
+    const int idx = wave_s + NW * i;
     if (idx >= NI1) return;                            // wave-uniform
     if (idx < NA) {
       __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR((WN_EXP & 4) ? zero16 : ss.asrc + idx * 1024 + lane * 16),
                                        WN_LDS_VOID(ss.sl + idx * 1024), 16, 0, 0);
     } else {
       const int bi = idx - NA;
-      const int gq = bi >= WN_NBLK ? 1 : 0, m = bi - gq * WN_NBLK;
+      const int gq = bi >= F_NBLK ? 1 : 0, m = bi - gq * F_NBLK;
       const int row = 8 * gq + (lane >> 3);
       const int t = ss.t4 + 32 * m + 4 * (lane & 7);
       bool ok = row < ss.c_count && t >= 0 && t < L;
-      if (m == WN_NBLK - 1) ok = ok && ss.spill && (lane & 7) == 0;
+      if (m == F_NBLK - 1) ok = ok && ss.spill && (lane & 7) == 0;
       if (WN_EXP & 2) ok = false;
       const char* src = ok ? reinterpret_cast<const char*>(ss.xb + ((long long)row * L + t)) : (row == ss.ones_row ? ones16 : zero16);
-      __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(ss.sl + WN_A_BYTES + gq * WN_GS + m * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(ss.sl + WN_A_BYTES + gq * F_GS + m * 1024), 16, 0, 0);
     }
   };
-  constexpr int NPW1 = (NI1 + 3) / 4;                  // pieces per wave per GEMM-1 stage (waves >= NI1 % 4 issue one fewer)
+  constexpr int NPW1 = (NI1 + NW - 1) / NW;            // pieces per wave per GEMM-1 stage (waves >= NI1 % NW issue one fewer)
+  static_assert(NPW1 <= 8, "the pieces of a stage are issued between the eight MFMA triples");
   auto issue = [&](int k, int slot) {
     const StageSrc ss = stage_src(k, slot);
 #pragma unroll
@@ -431,9 +436,9 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
   // wait until this wave's pieces of the stage about to be read have landed; `next` = the one stage issued after it
   auto wait_for = [&](int next, int S) {
     if (next >= S) wn_wait_vmcnt<0>();
-    else if (next < S1) { if (wave_s < (NI1 & 3)) wn_wait_vmcnt<(NI1 + 3) / 4>(); else wn_wait_vmcnt<NI1 / 4>(); }
-    else if (p.last) wn_wait_vmcnt<2>();
-    else wn_wait_vmcnt<4>();
+    else if (next < S1) { if (wave_s < (NI1 % NW)) wn_wait_vmcnt<(NI1 + NW - 1) / NW>(); else wn_wait_vmcnt<NI1 / NW>(); }
+    else if (p.last) wn_wait_vmcnt<8 / NW>();
+    else wn_wait_vmcnt<16 / NW>();
   };
 
   f32x16 acc[8];
@@ -477,9 +482,9 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
       shift = (tap_ - 1) * p.dil;
     }
     const int sub = (t0 + shift) & 3;
-    const char* base = ldsb + slot * WN_SLOT;
+    const char* base = ldsb + slot * F_SLOT;
     const int colx = wave_n0 + l31 + sub;
-    const char* bp = base + WN_A_BYTES + half * WN_GS + (colx >> 5) * 1024 + (colx & 31) * 4;
+    const char* bp = base + WN_A_BYTES + half * F_GS + (colx >> 5) * 1024 + (colx & 31) * 4;
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (WN_EXP & 32) ? (float)(k + j) : *reinterpret_cast<const float*>(bp + j * 128);
@@ -587,10 +592,10 @@ __global__ __launch_bounds__(256, 2) void wn_layer_fwd_kernel(WnFwdParams p) {
 #if !WN_INTERLEAVE
     if (more) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) issue_piece(nxt, i);
+      for (int i = 0; i < 16 / NW; ++i) issue_piece(nxt, i);
     }
 #endif
-    const char* base = ldsb + slot * WN_SLOT;
+    const char* base = ldsb + slot * F_SLOT;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
       if (!(p.last && mb < 4)) {                       // wave-uniform
@@ -649,10 +654,21 @@ extern "C" int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, i
   p.ts = ts; p.acts = acts; p.a_next = a_next; p.out = out;
   p.B = B; p.L = L; p.n = n; p.h = h; p.dil = dil; p.first = first ? 1 : 0; p.last = last ? 1 : 0;
   p.CH = wn_ch(n); p.CH2 = wn_ch2(h);
-  p.tiles_per_seq = (L + WN_TN - 1) / WN_TN;
+  // 256-sample tiles (8 waves) when they divide the sequence and still fill the chip, else 128-sample tiles (4 waves, two per CU)
+  static const int nw_env = getenv("FST_WN_FWD_NW") ? atoi(getenv("FST_WN_FWD_NW")) : 0;        // diagnostics: force 4 or 8
+  const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
+  int nw = (L % 256 == 0 && (long long)B * (L / 256) >= cus) ? 8 : 4;
+  if (nw_env == 4 || nw_env == 8) nw = nw_env;
+  const int tn = 32 * nw;
+  p.tiles_per_seq = (L + tn - 1) / tn;
   p.n_wg = B * p.tiles_per_seq;
-  if (int rc = fst_allow_full_lds((const void*)wn_layer_fwd_kernel, "fst_wn_layer_fwd")) return rc;
-  hipLaunchKernelGGL(wn_layer_fwd_kernel, dim3((unsigned)p.n_wg), dim3(256), WN_LDS_BYTES, (hipStream_t)stream, p);
+  if (nw == 8) {
+    if (int rc = fst_allow_full_lds((const void*)wn_layer_fwd_kernel<8>, "fst_wn_layer_fwd")) return rc;
+    hipLaunchKernelGGL(wn_layer_fwd_kernel<8>, dim3((unsigned)p.n_wg), dim3(512), WN_FWD_LDS(8), (hipStream_t)stream, p);
+  } else {
+    if (int rc = fst_allow_full_lds((const void*)wn_layer_fwd_kernel<4>, "fst_wn_layer_fwd")) return rc;
+    hipLaunchKernelGGL(wn_layer_fwd_kernel<4>, dim3((unsigned)p.n_wg), dim3(256), WN_FWD_LDS(4), (hipStream_t)stream, p);
+  }
   FST_LAUNCH_CHECK();
   return 0;
 }
