@@ -21,14 +21,14 @@ for dil in (1, 8, 128):
         lib.fst_debug_wn_stamps(None, 1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ops.wn_layer_fwd(a, u0, img, ts, acts, an, out, False, False, n, h, dil)
+        ops.wn_layer_fwd(a, u0, img, ts, None, an, out, False, False, n, h, dil)
         e1.record()
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 12)()
     lib.fst_debug_wn_stamps(buf, 1)
     waves = 1024 * 4
     tot = buf[9] / waves
-    print(f"== dil {dil}: {e0.elapsed_time(e1) * 1e3:.1f} us, {tot:.0f} cycles/wave (26 + 8 stages)")
+    print(f"== FST_WN_FWD_NW={os.environ.get('FST_WN_FWD_NW', 'auto')} dil {dil}: {e0.elapsed_time(e1) * 1e3:.1f} us, {tot:.0f} cycles/wave (26 + 8 stages)")
     for k in range(9):
         per = buf[k] / waves
         div = 26 if 1 <= k <= 5 else (8 if k == 7 else 1)
