@@ -1470,6 +1470,84 @@ class CouplingInvFn(torch.autograd.Function):
         return dx, d_o
 
 
+NT_SLICES = 32        # batch slices of the two-stage batch sums of NoiseTransferFn (fixed: the result does not depend on the device)
+
+
+def _scalar_arg(r):
+    """(device pointer or None, host float) of an accumulation ratio given as a Python number or a 0-d device tensor."""
+    if isinstance(r, Tensor):
+        if r.dtype != torch.float32 or not r.is_cuda or r.numel() != 1:
+            raise ValueError("a device ratio must be one fp32 element")
+        return ptr(r), 0.0
+    return None, float(r)
+
+
+class NoiseTransferFn(torch.autograd.Function):
+    """out = selu(W·((avg_t + r_t·mean_b z_t) − (avg_s + r_s·mean_b z_s)) + bias) + z_s   (/root/reference/widgets.py:150-167), the
+    running sums ``avg_t`` / ``avg_s`` ([C, L], detached state) updated in place — three launches (csrc/widgets.hip).
+    ``r_t`` / ``r_s``: Python floats or 0-d fp32 device tensors (a captured step refreshes them between replays)."""
+
+    @staticmethod
+    def forward(ctx, z_t, z_s, W, bias, avg_t, avg_s, r_t, r_s):
+        lib = _lib.load()
+        z_t, z_s = z_t.contiguous(), z_s.contiguous()
+        B, C, L = z_s.shape
+        N = C * L
+        if z_t.shape[1:] != z_s.shape[1:] or tuple(avg_t.shape) != (C, L) or tuple(avg_s.shape) != (C, L) or N % 4:
+            raise ValueError(f"NoiseTransferFn: z_t {tuple(z_t.shape)}, z_s {tuple(z_s.shape)}, state {tuple(avg_t.shape)} (C·L % 4 == 0)")
+        if not (avg_t.is_contiguous() and avg_s.is_contiguous()):
+            raise ValueError("NoiseTransferFn: the running sums must be contiguous (they are updated in place)")
+        W2 = W.reshape(C, C).contiguous()
+        bias = bias.contiguous()
+        if z_t.size(0) != B:
+            raise ValueError("NoiseTransferFn: the two batches must be equally large (the caller uses the ATen composition otherwise)")
+        dev = z_s.device
+        S = min(NT_SLICES, B)
+        part = torch.empty(2, S, N, device=dev, dtype=torch.float32)
+        check(lib.fst_batch_sum(ptr(z_t), ptr(z_s), ptr(part), B, N, S, stream_ptr()), "fst_batch_sum")
+        maps = torch.empty(3, C, L, device=dev, dtype=torch.float32)          # dist, pre, learned
+        (pt, ft), (ps, fs) = _scalar_arg(r_t), _scalar_arg(r_s)
+        check(lib.fst_noise_transfer_fwd(ptr(part), S, B, pt, ps, ft, fs, ptr(avg_t), ptr(avg_s), ptr(W2), ptr(bias), ptr(maps[0]),
+                                         ptr(maps[1]), ptr(maps[2]), C, L, stream_ptr()), "fst_noise_transfer_fwd")
+        out = torch.empty_like(z_s)
+        check(lib.fst_bcast_add(ptr(out), ptr(z_s), ptr(maps[2]), B, N, stream_ptr()), "fst_bcast_add")
+        ctx.save_for_backward(maps, W2, *[r for r in (r_t, r_s) if isinstance(r, Tensor)])
+        ctx.ratios = (r_t if not isinstance(r_t, Tensor) else None, r_s if not isinstance(r_s, Tensor) else None)
+        ctx.w_shape, ctx.B = W.shape, B
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        maps, W2 = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        extra = list(ctx.saved_tensors[2:])
+        r_t = ctx.ratios[0] if ctx.ratios[0] is not None else extra.pop(0)
+        r_s = ctx.ratios[1] if ctx.ratios[1] is not None else extra.pop(0)
+        g = g.contiguous()
+        B, C, L = g.shape
+        N = C * L
+        dev = g.device
+        S = min(NT_SLICES, B)
+        part = torch.empty(S, N, device=dev, dtype=torch.float32)
+        check(lib.fst_batch_sum(ptr(g), None, ptr(part), B, N, S, stream_ptr()), "fst_batch_sum")
+        small = torch.empty(2, C, L, device=dev, dtype=torch.float32)          # dpre, dd
+        check(lib.fst_noise_transfer_bwd(ptr(part), S, ptr(maps[1]), ptr(W2), ptr(small[0]), ptr(small[1]), C, L, stream_ptr()),
+              "fst_noise_transfer_bwd")
+        dW = db = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dW = torch.empty(C, C, device=dev, dtype=torch.float32)
+            db = torch.empty(C, device=dev, dtype=torch.float32)
+            check(lib.fst_noise_transfer_dw(ptr(small[0]), ptr(maps[0]), ptr(dW), ptr(db), C, L, stream_ptr()), "fst_noise_transfer_dw")
+            dW = dW.view(ctx.w_shape)
+        dz_t = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        dz_s = torch.empty_like(g) if ctx.needs_input_grad[1] else None
+        if dz_t is not None or dz_s is not None:
+            (pt, ft), (ps, fs) = _scalar_arg(r_t), _scalar_arg(r_s)
+            check(lib.fst_noise_transfer_bwd_apply(ptr(g), ptr(small[1]), pt, ps, ft, fs, B, ptr(dz_t), ptr(dz_s), N, stream_ptr()),
+                  "fst_noise_transfer_bwd_apply")
+        return dz_t, dz_s, dW, db, None, None, None, None
+
+
 class LogDetFn(torch.autograd.Function):
     """log det W of a square fp32 matrix with torch.logdet's conventions (NaN for det < 0, -inf for det = 0), forward and the
     gradient W^{-T} from ONE single-workgroup launch (fst_logdet_inv) — Simplified_NF_WaveGlow.py:40."""

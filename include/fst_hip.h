@@ -280,6 +280,28 @@ int fst_wn_wgrad_rs(const float* const* d_a /* NULL iff last */, const float* co
                     float* dw_rs, float* workspace, int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a,
                     void* stream);
 
+/* NoiseTransfer (/root/reference/widgets.py:150-167): new_t = avg_t + r_t·mean_b(z_t), new_s likewise, dist = new_t − new_s,
+ * learned = selu(W·dist + bias) (unbatched 1x1 conv over the [C, L] map), out[b] = learned + z_s[b].
+ *   fst_batch_sum            part[z][s][i] = Σ_{b in slice s} x_z[b][i] (z < 2 tensors, x1 may be NULL; S contiguous slices of the
+ *                            batch, N = C·L, N % 4 == 0) — partials added in slice order by the consumers: deterministic
+ *   fst_noise_transfer_fwd   slice sums [2][S][C·L] → avg_t, avg_s updated IN PLACE (the reference's detached state), dist, pre = W·dist +
+ *                            bias and learned = selu(pre) written ([C][L] each).  r_*_dev: the call's accumulation ratios as device
+ *                            scalars (a captured step refreshes them between replays) or NULL: the host values r_t, r_s
+ *   fst_bcast_add            out[b][i] = x[b][i] + v[i]
+ *   fst_noise_transfer_bwd   slice sums [S][C·L] of the cotangent of out → dpre = Σ_b g · selu'(pre), dd = Wᵀ·dpre (cotangent of dist)
+ *   fst_noise_transfer_dw    dW[o][c] = Σ_l dpre[o][l]·dist[c][l], dbias[o] = Σ_l dpre[o][l]
+ *   fst_noise_transfer_bwd_apply   dz_t[b] = (r_t/B)·dd,  dz_s[b] = g[b] − (r_s/B)·dd  (either output may be NULL) */
+int fst_batch_sum(const float* x0, const float* x1, float* part, int B, int64_t N, int S, void* stream);
+int fst_noise_transfer_fwd(const float* part, int S, int B, const float* r_t_dev, const float* r_s_dev, float r_t, float r_s,
+                           float* avg_t, float* avg_s, const float* W, const float* bias, float* dist, float* pre, float* learned,
+                           int C, int L, void* stream);
+int fst_bcast_add(float* out, const float* x, const float* v, int B, int64_t N, void* stream);
+int fst_noise_transfer_bwd(const float* part, int S, const float* pre, const float* W, float* dpre, float* dd, int C, int L,
+                           void* stream);
+int fst_noise_transfer_dw(const float* dpre, const float* dist, float* dW, float* dbias, int C, int L, void* stream);
+int fst_noise_transfer_bwd_apply(const float* g, const float* dd, const float* r_t_dev, const float* r_s_dev, float r_t, float r_s,
+                                 int B, float* dz_t, float* dz_s, int64_t N, void* stream);
+
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */
 int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,

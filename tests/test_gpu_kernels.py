@@ -601,3 +601,38 @@ def test_logdet_and_inverse_transpose_kernel(n):
         sing = float(ops.logdet(Ws.float().to(DEV)))
         assert sing == float("-inf") or sing != sing or sing < -25.0
         assert float(ops.logdet(torch.zeros(n, n, device=DEV))) == float("-inf")   # an exactly zero pivot
+
+
+@pytest.mark.parametrize("B,C,L,device_ratios", [(256, 50, 512, False), (7, 6, 10, True), (33, 50, 64, True), (3, 5, 4, False)])
+def test_noise_transfer_kernels_vs_fp64_composition(B, C, L, device_ratios):
+    """csrc/widgets.hip (ops.NoiseTransferFn) against the reference's composition (widgets.py:150-167) in fp64: output, the
+    in-place running sums, and the gradients of both latent batches and of the 1x1 conv; bit-identical when repeated."""
+    g = torch.Generator(device=DEV).manual_seed(B + C + L)
+    rnd = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    z_t, z_s = rnd(B, C, L).requires_grad_(True), rnd(B, C, L).requires_grad_(True)
+    W, bias = (rnd(C, C, 1) * 0.2).requires_grad_(True), (rnd(C) * 0.1).requires_grad_(True)
+    avg_t0, avg_s0 = rnd(C, L), rnd(C, L)
+    r = (0.37, 1.9)
+    cot = rnd(B, C, L)
+
+    def run():
+        avg_t, avg_s = avg_t0.clone(), avg_s0.clone()
+        rr = tuple(torch.tensor(v, device=DEV) for v in r) if device_ratios else r
+        out = ops.NoiseTransferFn.apply(z_t, z_s, W, bias, avg_t, avg_s, rr[0], rr[1])
+        grads = torch.autograd.grad(out, (z_t, z_s, W, bias), cot)
+        return out.detach(), avg_t, avg_s, grads
+
+    out, avg_t, avg_s, grads = run()
+    zt64, zs64 = z_t.detach().double().requires_grad_(True), z_s.detach().double().requires_grad_(True)
+    W64, b64 = W.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    nt = avg_t0.double() + r[0] * zt64.mean(0)
+    ns = avg_s0.double() + r[1] * zs64.mean(0)
+    want = F.selu(F.conv1d((nt - ns)[None], W64, b64))[0] + zs64
+    wg = torch.autograd.grad(want, (zt64, zs64, W64, b64), cot.double())
+    assert_close(out, want.detach(), 1e-5, "NoiseTransfer out")
+    assert_close(avg_t, nt.detach(), 1e-6, "running sum (target)")
+    assert_close(avg_s, ns.detach(), 1e-6, "running sum (source)")
+    for got, ref, name in zip(grads, wg, ("dz_t", "dz_s", "dW", "dbias")):
+        assert_close(got, ref, 2e-5, name)
+    out2, avg_t2, avg_s2, grads2 = run()
+    assert torch.equal(out, out2) and torch.equal(avg_t, avg_t2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
