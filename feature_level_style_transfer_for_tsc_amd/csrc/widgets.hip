@@ -227,3 +227,27 @@ extern "C" int fst_noise_transfer_bwd_apply(const float* g, const float* dd, con
   FST_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- ReLU backward for epilogue-fused ReLUs
+// DimensionUnification (widgets.py:73-78 of the reference) runs its two ReLUs in the epilogues of the length GEMM and of the 1x1 conv;
+// their backward needs dy·[y > 0] once, in front of the data / weight gradient GEMMs:  out[i] = y[i] > 0 ? dy[i] : 0
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* dy, const float* y, float* out, long long n4, long long n) {
+  for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n4; j += (long long)gridDim.x * 256) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[j], v = reinterpret_cast<const float4*>(y)[j];
+    reinterpret_cast<float4*>(out)[j] = {v.x > 0.f ? g.x : 0.f, v.y > 0.f ? g.y : 0.f, v.z > 0.f ? g.z : 0.f, v.w > 0.f ? g.w : 0.f};
+  }
+  if (blockIdx.x == 0)
+    for (long long i = 4 * n4 + threadIdx.x; i < n; i += 256) out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+extern "C" int fst_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream) {
+  FST_REQUIRE(dy && y && out && n > 0, "fst_relu_bwd: bad arguments");
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  FST_REQUIRE(al16(dy) && al16(y) && al16(out), "fst_relu_bwd: tensors must be 16-byte aligned");
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, out, (long long)(n / 4), (long long)n);
+  FST_LAUNCH_CHECK();
+  return 0;
+}

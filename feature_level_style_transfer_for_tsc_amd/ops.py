@@ -567,6 +567,61 @@ def conv1d(spec: ConvSpec, x: Tensor, w: Tensor, bias: Optional[Tensor]) -> Tens
     return ConvFn.apply(spec, x, w, bias)
 
 
+def relu_bwd(dy: Tensor, y: Tensor) -> Tensor:
+    """dy·[y > 0] — the backward of a ReLU that ran in a GEMM / conv epilogue (``y`` = its output)."""
+    dy = dy.contiguous()
+    out = torch.empty_like(dy)
+    check(_lib.load().fst_relu_bwd(ptr(dy), ptr(y), ptr(out), _same_numel(dy, y), stream_ptr()), "fst_relu_bwd")
+    return out
+
+
+class ConvReluFn(torch.autograd.Function):
+    """relu(conv1d(x, w) + bias), the ReLU in the GEMM epilogue (DimensionUnification's channel conv, widgets.py:76-77)."""
+
+    @staticmethod
+    def forward(ctx, spec: ConvSpec, x: Tensor, w: Tensor, bias: Optional[Tensor]):
+        y = spec.forward(x, None, w, None, bias, flags=EPI_RELU)
+        ctx.spec, ctx.has_bias = spec, bias is not None
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec: ConvSpec = ctx.spec
+        x, w, y = ctx.saved_tensors
+        g = relu_bwd(dy, y)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dx = spec.grad_x0(g, w)
+        if ctx.needs_input_grad[2] and _want_weight_grad(spec):
+            dw, _ = spec.grad_w(x, None, g)
+        if ctx.has_bias and ctx.needs_input_grad[3] and _want_weight_grad(spec):
+            db = row_sum(g)
+        return None, dx, dw, db
+
+
+class LinearReluFn(torch.autograd.Function):
+    """relu(x @ Wᵀ + b) over the last dimension, bias and ReLU in the hipBLASLt epilogue (one kernel: DimensionUnification's length
+    GEMM, widgets.py:73-75; a plain library GEMM, as the hot-path rules allow)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, W: Tensor, b: Tensor):
+        x2 = x.reshape(-1, x.size(-1)).contiguous()
+        y = torch._addmm_activation(b, x2, W.t(), use_gelu=False)
+        ctx.save_for_backward(x2, W, y)
+        ctx.lead = x.shape[:-1]
+        return y.view(*ctx.lead, W.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W, y = ctx.saved_tensors
+        g = relu_bwd(dy.reshape(y.shape), y)
+        dx = (g @ W).view(*ctx.lead, W.size(1)) if ctx.needs_input_grad[0] else None
+        dW = g.t() @ x2 if ctx.needs_input_grad[1] and _want_weight_grad() else None
+        db = g.sum(dim=0) if ctx.needs_input_grad[2] and _want_weight_grad() else None
+        return dx, dW, db
+
+
 def mask_taps_(w: Tensor, lo: Tensor, hi: Tensor) -> None:
     """W ← W ⊙ mask in place on ``w.data`` (OS_CNN.py:68 re-masks ``.data`` every forward)."""
     lib = _lib.load()

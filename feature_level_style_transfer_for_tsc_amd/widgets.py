@@ -83,6 +83,10 @@ class DimensionUnification(nn.Module):
         self.spec = ops.ConvSpec(target_channel, source_channel)
 
     def forward(self, source_feature):
+        if source_feature.is_cuda and source_feature.dtype == torch.float32:
+            # both ReLUs in the epilogues of their GEMMs: two launches for the module
+            h = ops.LinearReluFn.apply(source_feature, self.length_unification.weight, self.length_unification.bias)
+            return ops.ConvReluFn.apply(self.spec, h, self.channel_unification.weight, self.channel_unification.bias)
         h = self.relu1(self.length_unification(source_feature))
         h = ops.conv1d(self.spec, h.contiguous(), self.channel_unification.weight, self.channel_unification.bias)
         return self.relu2(h)

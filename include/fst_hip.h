@@ -303,6 +303,7 @@ int fst_noise_transfer_bwd_apply(const float* g, const float* dd, const float* r
                                  int B, float* dz_t, float* dz_s, int64_t N, void* stream);
 
 /* generic fp32 elementwise helpers on contiguous buffers */
+int fst_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream);   /* out = dy·[y > 0] (epilogue-fused ReLUs) */
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */
 int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,
                    int B, int C, int L, void* stream);                                  /* dst = a + b (b may be null) */

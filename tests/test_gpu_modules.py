@@ -612,3 +612,22 @@ def test_wn_other_depths_and_kernel_sizes_vs_oracle(n_layers, kernel, fused_expe
     close(out, want, 1e-4, "WN output")
     close(ud.grad, uo.grad, 1e-3, "WN d input")
     check_grads(wn, {k[5:]: v.grad.numpy() for k, v in P.items() if v.grad is not None}, 1e-3, f"WN({n_layers} layers, k={kernel}) ")
+
+
+def test_dimension_unification_fused_relus_vs_composition():
+    """DimensionUnification with both ReLUs in the GEMM / conv epilogues (ops.LinearReluFn, ops.ConvReluFn) against the reference's
+    composition relu(conv1x1(relu(linear(x)))) (widgets.py:66-78) in fp64: output and every gradient."""
+    torch.manual_seed(5)
+    du = fst.DimensionUnification(25, 50, 96, 64).to(DEV)
+    x = torch.randn(9, 25, 96, device=DEV, requires_grad=True)
+    cot = torch.randn(9, 50, 64, device=DEV)
+    y = du(x)
+    got = torch.autograd.grad(y, [x] + list(du.parameters()), cot)
+    P = {k: v.detach().double().requires_grad_(True) for k, v in du.named_parameters()}
+    x64 = x.detach().double().requires_grad_(True)
+    h = torch.relu(F.linear(x64, P["length_unification.weight"], P["length_unification.bias"]))
+    want = torch.relu(F.conv1d(h, P["channel_unification.weight"], P["channel_unification.bias"]))
+    wg = torch.autograd.grad(want, [x64] + [P[k] for k, _ in du.named_parameters()], cot.double())
+    close(y, want.detach().cpu().numpy(), 1e-5, "dimunif out")
+    for a, b, name in zip(got, wg, ["dx"] + [k for k, _ in du.named_parameters()]):
+        close(a, b.detach().cpu().numpy(), 1e-4, name)
