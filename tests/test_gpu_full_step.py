@@ -123,6 +123,16 @@ def _head_unit_branches(record=None, impose=None, flips=None):
             record.append((out.detach() > 0).cpu())
             return out
         _ops.BNActFn.apply, _ops.BNAddBNReluFn.apply = bn_act_rec, bn_join_rec
+        # the dimension unification's two ReLUs run in the epilogues of its GEMM and of its 1x1 conv
+        lin_relu, conv_relu = _ops.LinearReluFn.apply, _ops.ConvReluFn.apply
+
+        def epi_rec(fn):
+            def wrapped(*a):
+                out = fn(*a)
+                record.append((out.detach() > 0).cpu())
+                return out
+            return wrapped
+        _ops.LinearReluFn.apply, _ops.ConvReluFn.apply = epi_rec(lin_relu), epi_rec(conv_relu)
     try:
         yield
         if it is not None:
@@ -131,6 +141,7 @@ def _head_unit_branches(record=None, impose=None, flips=None):
         F.relu, F.leaky_relu, R.dimension_unification = relu0, leaky0, dimunif0
         if record is not None:
             del _ops.BNActFn.apply, _ops.BNAddBNReluFn.apply       # back to the inherited Function.apply
+            del _ops.LinearReluFn.apply, _ops.ConvReluFn.apply
 
 
 def _step_both(js, tr, batch, ts):
