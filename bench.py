@@ -382,7 +382,7 @@ def main() -> None:
         conv_ms = sum(v["total_ms"] for v in ks.values()) / n_timer_steps
         traffic, traffic_src = None, None
         # PMC passes cannot run inside bench.py: the newest committed counter summary that covers this kernel
-        for tname in ("traffic_r02.json", "traffic_r01.json"):
+        for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
