@@ -1,4 +1,4 @@
-"""The bench line recorded on the MI355X (profiles/r02_bench_line.txt) carries every field of the driver's contract."""
+"""The bench line recorded on the MI355X (profiles/r03_bench_line.txt) carries every field of the driver's contract."""
 import json
 import os
 
@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_recorded_bench_line_has_the_contract_fields():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_line.txt")).read())
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_line.txt")).read())
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"] == base["metric"] and d["unit"] == "samples/s"
     for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
