@@ -47,6 +47,14 @@ class RandomLayer(nn.Module):
         return self._transposed[i]
 
     def forward(self, input_list):
+        if self.input_num == 2:
+            x, pr = input_list
+            R0, R1 = self.random_matrix
+            if (x.dim() == 2 and R0.shape[0] >= 256 and not R1.requires_grad
+                    and ops.nt_gemm_ok(x.shape[0], R0.shape[1], R0.shape[0], x.contiguous(), R0, self._rt(0))
+                    and ops.nt_gemm_ok(x.shape[0], R0.shape[0], R0.shape[1], R0)):
+                # one GEMM with the class-side product, the 1/√O scale and the Hadamard product in its epilogue
+                return ops.RandomLayerFn.apply(x, pr, R0, self._rt(0), R1.contiguous(), 1.0 / math.pow(float(self.output_dim), 0.5))
         outs = []
         for i in range(self.input_num):
             R = self.random_matrix[i]

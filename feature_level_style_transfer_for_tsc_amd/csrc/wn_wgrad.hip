@@ -59,6 +59,13 @@ struct WwParams {
   int xr;               // staged k-rows per group = 32·2·KT
   int mul;              // 1: every k-row is staged twice (row and partner) and multiplied when its fragment is read
   int n_groups, ksplit, B, L, tiles_per_seq, n_tiles;   // n_tiles: per operand set
+  // fst_nt_gemm only — RandomLayer's epilogue (C_DAN.py:20-25): C[m][n] = acc·epi_scale·Σ_c epi_p[m][c]·epi_r1[c][n], the plain product
+  // acc kept in epi_raw (the backward needs it); all null / 0 for the weight gradients
+  const float* epi_p;
+  const float* epi_r1;
+  float* epi_raw;
+  int epi_ncls;
+  float epi_scale;
   int n_sets;           // operand sets whose gradients are SUMMED (the applications of one WN in a train step share their weights:
                         // one launch, one set of slabs and one reduction for all of them); workgroup x works on set x % n_sets
   int RX;               // staged rows of a k-row slot: xr·(1 + mul) (+ 8 for the leftover rows), a multiple of 8
@@ -468,7 +475,14 @@ __device__ __forceinline__ void ww_scatter(const WwParams& p, int m, int kk, flo
   if (si == 2) { out = p.x[2].out; off = p.x[2].out_off; sc = p.x[2].out_sc; sm = p.x[2].out_sm; }
   if (si == 3) { out = p.x[3].out; off = p.x[3].out_off; sc = p.x[3].out_sc; sm = p.x[3].out_sm; }
   float* w = out == 0 ? p.w[0] : p.w[1];
-  w[(long long)m * sm + (long long)c * sc + off] = v;
+  const long long at = (long long)m * sm + (long long)c * sc + off;
+  if (p.epi_p) {                                          // (uniform) RandomLayer: Hadamard product with the class-side map, scaled
+    float sd = 0.f;
+    for (int j = 0; j < p.epi_ncls; ++j) sd += p.epi_p[m * p.epi_ncls + j] * p.epi_r1[(long long)j * sm + c];
+    if (p.epi_raw) p.epi_raw[at] = v;
+    v = v * p.epi_scale * sd;
+  }
+  w[at] = v;
 }
 
 __global__ __launch_bounds__(256) void wn_wgrad_reduce_kernel(WwParams p) {
@@ -569,8 +583,10 @@ static int ww_launch(WwParams& p, int KT, void* stream) {
   if (KT == 3) {
     if (p.n_extra) fn = full ? wn_wgrad_kernel<2, 3, true, false, 1> : wn_wgrad_kernel<2, 3, false, false, 1>;
     else fn = full ? wn_wgrad_kernel<2, 3, true, false, 0> : wn_wgrad_kernel<2, 3, false, false, 0>;
-  } else {
+  } else if (p.mul) {
     fn = full ? wn_wgrad_kernel<2, 2, true, true, 0> : wn_wgrad_kernel<2, 2, false, true, 0>;
+  } else {
+    fn = full ? wn_wgrad_kernel<2, 2, true, false, 0> : wn_wgrad_kernel<2, 2, false, false, 0>;
   }
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_wn_wgrad")) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
@@ -642,4 +658,57 @@ extern "C" int fst_wn_wgrad_rs(const float* const* d_a, const float* const* d_ou
   p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
   p.w[0] = dw_rs; p.w[1] = nullptr;
   return ww_launch(p, KT, stream);
+}
+
+// ------------------------------------------------------------------------------------------------ C = A·Bᵀ on the same kernel
+// C[m][n] = Σ_k A[m][k]·Bm[n][k]: both operands row-major with the reduction index contiguous — exactly the weight-gradient
+// product above with A's rows as the output rows, Bm's rows as the k-rows and k as "time" (one sequence of K samples).
+// RandomLayer's feature-side GEMM (C_DAN.py:21: [B, 25 600] × the fixed [25 600, 1024] Gaussian, kept transposed) and its data
+// gradient ([B, 1024] × the matrix as it is) are both of this form; the 105 MB matrix is read once from HBM by the LDS-DMA ring,
+// the K split leaves partial slabs that the reduce kernel adds in a fixed order (no atomics) while applying the layer's epilogue.
+extern "C" int64_t fst_nt_gemm_workspace_floats(int M, int N, int K) {
+  if (!(M > 0 && M <= WW_MROWS && N > 0 && K > 0 && K % WW_TT == 0)) return -1;
+  const int n_groups = ((N + 31) / 32 + 3) / 4;
+  const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
+  int ks = cus / n_groups;
+  if (ks > K / WW_TT) ks = K / WW_TT;
+  if (ks < 1) ks = 1;
+  return (int64_t)ks * WW_MROWS * (n_groups * 128 + 2);
+}
+
+extern "C" int fst_nt_gemm(const float* A, const float* Bm, float* C, float* workspace, int64_t workspace_floats, int M, int N, int K,
+                           const float* epi_p, const float* epi_r1, int epi_ncls, float epi_scale, float* epi_raw, void* stream) {
+  FST_REQUIRE(A && Bm && C && workspace, "fst_nt_gemm: null operand");
+  FST_REQUIRE(M > 0 && M <= WW_MROWS && N > 0 && K > 0 && K % WW_TT == 0, "fst_nt_gemm: M=%d N=%d K=%d (needs M <= 256, K %% 32 == 0)", M, N, K);
+  FST_REQUIRE((long long)N * K < (1LL << 31) * 4 && (long long)M * N < (1LL << 31), "fst_nt_gemm: operand too large");
+  FST_REQUIRE(ww_al16(A) && ww_al16(Bm) && ww_al16(workspace), "fst_nt_gemm: operands must be 16-byte aligned");
+  FST_REQUIRE((epi_p == nullptr) == (epi_r1 == nullptr) && (epi_p == nullptr || epi_ncls > 0) && (epi_p != nullptr || epi_raw == nullptr),
+              "fst_nt_gemm: the epilogue takes p [M][ncls] and r1 [ncls][N] together (and the raw product only with them)");
+  WwParams p = {};
+  p.M = M; p.K = N; p.K_main = N; p.n_extra = 0;
+  p.xr = 128;
+  p.n_groups = ((N + 31) / 32 + 3) / 4;
+  p.mul = 0;
+  p.RX = p.xr;
+  p.Kcols = p.n_groups * p.xr;
+  p.B = 1; p.L = K;
+  p.tiles_per_seq = K / WW_TT;
+  p.n_tiles = p.tiles_per_seq;
+  const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
+  int ks = cus / p.n_groups;
+  if (ks > p.n_tiles) ks = p.n_tiles;
+  if (ks < 1) ks = 1;
+  p.ksplit = ks;
+  p.n_sets = 1;
+  FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2), "fst_nt_gemm: workspace of %lld floats is too small",
+              (long long)workspace_floats);
+  p.n_dy = 1;
+  p.dy[0] = {{A, nullptr, nullptr}, 0, 0, M, 0, 0, 0, 0, 0};
+  p.n_x = 1;
+  p.x[0] = {{Bm, nullptr, nullptr}, 0, 0, N, 0, 0, 0, 1, N};              // C[m][n] at w[0][m·N + n]
+  p.slab = workspace;
+  p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
+  p.w[0] = C; p.w[1] = nullptr;
+  p.epi_p = epi_p; p.epi_r1 = epi_r1; p.epi_ncls = epi_ncls; p.epi_scale = epi_scale; p.epi_raw = epi_raw;
+  return ww_launch(p, 2, stream);
 }

@@ -1765,6 +1765,60 @@ class LSTM2Fn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------
 # CDAN random multilinear map: x[B, D] @ R[D, O] with R fixed
 # --------------------------------------------------------------------------------------------------
+def nt_gemm_ok(M: int, N: int, K: int, *ts: Tensor) -> bool:
+    """Whether ``nt_gemm`` serves C[M, N] = A[M, K]·Bm[N, K]ᵀ: at most 256 rows, K a multiple of 32, 16-byte aligned fp32 operands."""
+    return (0 < M <= 256 and K % 32 == 0 and MATH == "bf16x3"
+            and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts))
+
+
+def nt_gemm(A: Tensor, Bm: Tensor, epi: Optional[Tuple[Tensor, Tensor, float]] = None, want_raw: bool = False):
+    """C = A·Bmᵀ for row-major A [M, K], Bm [N, K] (fst_nt_gemm: split-bf16 products, K split into slabs added in a fixed order).
+    ``epi`` = (p [M, ncls], r1 [ncls, N], scale): C = (A·Bmᵀ)·scale·(p·r1) — RandomLayer's epilogue; ``want_raw``: also return A·Bmᵀ."""
+    lib = _lib.load()
+    M, K = A.shape
+    N = Bm.shape[0]
+    if Bm.shape[1] != K or not nt_gemm_ok(M, N, K, A, Bm):
+        raise ValueError(f"nt_gemm: A {tuple(A.shape)}, Bm {tuple(Bm.shape)} (M <= 256, K % 32 == 0, contiguous fp32 on the GPU, split-bf16 mode)")
+    C = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    ws_n = lib.fst_nt_gemm_workspace_floats(M, N, K)
+    ws = torch.empty(ws_n, device=A.device, dtype=torch.float32)
+    raw = torch.empty_like(C) if (want_raw and epi is not None) else None
+    p_, r1, scale = (None, None, 1.0) if epi is None else epi
+    if epi is not None and (tuple(p_.shape) != (M, r1.shape[0]) or r1.shape[1] != N or not p_.is_contiguous() or not r1.is_contiguous()):
+        raise ValueError("nt_gemm: epilogue operands must be contiguous p [M, ncls], r1 [ncls, N]")
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_nt_gemm(ptr(A), ptr(Bm), ptr(C), ptr(ws), ws_n, M, N, K, ptr(p_), ptr(r1), 0 if epi is None else r1.shape[0], float(scale),
+                          ptr(raw), stream_ptr()), "fst_nt_gemm")
+    if t0 is not None:
+        KERNEL_TIMER.end("nt_gemm (wn_wgrad_kernel<2, 2>) bf3", t0, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N))
+    return (C, raw) if want_raw else C
+
+
+class RandomLayerFn(torch.autograd.Function):
+    """RandomLayer.forward for two inputs (C_DAN.py:18-25):  (x·R₀ / √O) ⊙ (p·R₁)  with fixed Gaussian R₀ [D, O], R₁ [ncls, O] — the
+    feature-side product on the matrix cores with the class-side product, the scale and the Hadamard product in its epilogue
+    (one pass over the [B, O] result).  ``R0t`` = R₀ᵀ kept contiguous (the forward's operand); the backward's is R₀ itself."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, p: Tensor, R0: Tensor, R0t: Tensor, R1: Tensor, scale: float):
+        x, p = x.contiguous(), p.contiguous()
+        out, y0 = nt_gemm(x, R0t, (p, R1, scale), want_raw=True)
+        ctx.save_for_backward(p, R0, R1, y0)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, R0, R1, y0 = ctx.saved_tensors
+        g = g.contiguous() * ctx.scale
+        dx = dp = None
+        if ctx.needs_input_grad[0]:
+            dx = nt_gemm(g * (p @ R1), R0)                       # (dy ⊙ s / √O)·R₀ᵀ
+        if ctx.needs_input_grad[1]:
+            dp = (g * y0) @ R1.t()
+        return dx, dp, None, None, None, None
+
+
 class FixedMatmulFn(torch.autograd.Function):
     """y = x @ R for a fixed (non-trainable) R — RandomLayer's big GEMM (C_DAN.py:21).  R is streamed
     once through LDS as the B operand; x is packed as the A operand; K is split across workgroups."""

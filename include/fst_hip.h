@@ -280,6 +280,16 @@ int fst_wn_wgrad_rs(const float* const* d_a /* NULL iff last */, const float* co
                     float* dw_rs, float* workspace, int64_t workspace_floats, int last, int B, int L, int n, int64_t numel_a,
                     void* stream);
 
+/* C[m][n] = Σ_k A[m][k]·Bm[n][k]  (A [M][K], Bm [N][K] row-major, the reduction index contiguous in both; M <= 256, K % 32 == 0) on the
+ * time-as-k kernel above: RandomLayer's feature-side product x·R₀ (/root/reference/C_DAN.py:21; Bm = R₀ᵀ kept contiguous) and its data
+ * gradient dy·R₀ᵀ (Bm = R₀).  The K split leaves partial slabs in `workspace` (fst_nt_gemm_workspace_floats), added in a fixed order.
+ * Optional epilogue = the rest of RandomLayer.forward (C_DAN.py:22-25): C[m][n] = acc·epi_scale·Σ_c epi_p[m][c]·epi_r1[c][n] with the
+ * plain product acc stored in epi_raw (may be NULL); epi_p = epi_r1 = NULL: C = acc. */
+int64_t fst_nt_gemm_workspace_floats(int M, int N, int K);
+int fst_nt_gemm(const float* A, const float* Bm, float* C, float* workspace, int64_t workspace_floats, int M, int N, int K,
+                const float* epi_p /* [M][ncls] */, const float* epi_r1 /* [ncls][N] */, int epi_ncls, float epi_scale,
+                float* epi_raw /* [M][N] */, void* stream);
+
 /* NoiseTransfer (/root/reference/widgets.py:150-167): new_t = avg_t + r_t·mean_b(z_t), new_s likewise, dist = new_t − new_s,
  * learned = selu(W·dist + bias) (unbatched 1x1 conv over the [C, L] map), out[b] = learned + z_s[b].
  *   fst_batch_sum            part[z][s][i] = Σ_{b in slice s} x_z[b][i] (z < 2 tensors, x1 may be NULL; S contiguous slices of the

@@ -636,3 +636,34 @@ def test_noise_transfer_kernels_vs_fp64_composition(B, C, L, device_ratios):
         assert_close(got, ref, 2e-5, name)
     out2, avg_t2, avg_s2, grads2 = run()
     assert torch.equal(out, out2) and torch.equal(avg_t, avg_t2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 25600), (256, 25600, 1024), (3, 5, 32), (200, 130, 96), (33, 129, 64), (1, 1, 32)])
+def test_nt_gemm_vs_fp64(M, N, K):
+    """fst_nt_gemm (C = A·Bmᵀ on the time-as-k kernel, K split into slabs added in a fixed order) against fp64; bit-identical twice."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A, Bm = torch.randn(M, K, generator=g, device=DEV), torch.randn(N, K, generator=g, device=DEV)
+    C = ops.nt_gemm(A, Bm)
+    assert_close(C, A.double() @ Bm.double().t(), 2e-5, f"nt_gemm {M}x{N}x{K}")
+    assert torch.equal(C, ops.nt_gemm(A, Bm))
+    with pytest.raises(ValueError):
+        ops.nt_gemm(A[:, : K - 1].contiguous(), Bm[:, : K - 1].contiguous())           # K % 32 != 0
+
+
+@pytest.mark.parametrize("Bq,D,O,ncls", [(256, 25600, 1024, 4), (7, 288, 96, 3)])
+def test_random_layer_fused_vs_composition(Bq, D, O, ncls):
+    """ops.RandomLayerFn (the product, the 1/√O scale and the Hadamard product with p·R₁ in one GEMM epilogue) against the
+    reference's composition (C_DAN.py:18-25) in fp64, forward and both input gradients."""
+    g = torch.Generator(device=DEV).manual_seed(Bq + D)
+    x = torch.randn(Bq, D, generator=g, device=DEV, requires_grad=True)
+    p = torch.softmax(torch.randn(Bq, ncls, generator=g, device=DEV), 1).requires_grad_(True)
+    R0, R1 = torch.randn(D, O, generator=g, device=DEV), torch.randn(ncls, O, generator=g, device=DEV)
+    cot = torch.randn(Bq, O, generator=g, device=DEV)
+    out = ops.RandomLayerFn.apply(x, p, R0, R0.t().contiguous(), R1, 1.0 / O ** 0.5)
+    gx, gp = torch.autograd.grad(out, (x, p), cot)
+    x64, p64 = x.detach().double().requires_grad_(True), p.detach().double().requires_grad_(True)
+    want = (x64 @ R0.double()) / O ** 0.5 * (p64 @ R1.double())
+    wx, wp = torch.autograd.grad(want, (x64, p64), cot.double())
+    assert_close(out, want, 2e-5, "random layer out")
+    assert_close(gx, wx, 2e-5, "random layer dx")
+    assert_close(gp, wp, 2e-5, "random layer dp")
