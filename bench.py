@@ -219,7 +219,7 @@ def north_star_extras(fst, ops, trainer, x_t, B: int, L: int):
         out["omni_scale_fe_forward"] = {
             "ms": ms, "algorithmic_GBps": 4.0 * (C_in + C) * B * L / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
             "TFLOPps": 2.0 * macs * B * L / (ms * 1e-3) / 1e12,
-            "counters": "profiles/r02_omni_hbm_traffic.csv, profiles/r02_omni_mfma_busy.csv (rocprofv3 --pmc passes on tools/north_star_micro.py)",
+            "counters": "profiles/r03_north_star_micro_hbm_traffic.csv, profiles/r03_north_star_micro_mfma_busy.csv (rocprofv3 --pmc passes on tools/north_star_micro.py)",
             "note": "OS_CNN_res forward incl. train-mode BatchNorm passes; layer 1 (216 900 live MACs/timestep) runs on "
                     "conv_win_bf3_kernel — see roofline.kernels for its own rate; the block is compute-bound, the GB/s "
                     "figure is input + features once"}
@@ -227,19 +227,26 @@ def north_star_extras(fst, ops, trainer, x_t, B: int, L: int):
         T = L // 2
         pred = torch.randn(T, B, C, device=x_t.device) * 0.3
         ms = _timed(lambda: ops.CPCNceFn.apply(feat, pred, 7, T))
-        out["cpc_cross_gram"] = {"ms": ms, "counters": "profiles/r02_cpc_hbm_traffic.csv, profiles/r02_cpc_mfma_busy.csv", "TFLOPps": 2.0 * T * B * B * C / (ms * 1e-3) / 1e12, "peak_TFLOPps": 157.3,
+        out["cpc_cross_gram"] = {"ms": ms, "counters": "profiles/r03_north_star_micro_hbm_traffic.csv, profiles/r03_north_star_micro_mfma_busy.csv", "TFLOPps": 2.0 * T * B * B * C / (ms * 1e-3) / 1e12, "peak_TFLOPps": 157.3,
                                  "note": "all T cross-Grams enc_i·pred_iT (K = C = 50) on v_mfma_f32_32x32x2_f32 (exact fp32), "
                                          "log-softmax + diagonal fused on the accumulators; priced against the f32 MFMA peak"}
         rl = trainer.random_layer
         xf = torch.randn(B, C * L, device=x_t.device)
-        R0 = rl.random_matrix[0]
-        ms = _timed(lambda: ops._fixed_matmul(xf, R0, B, C * L, R0.size(1)))
+        R0, R1 = rl.random_matrix[0], rl.random_matrix[1]
+        R0t = rl._rt(0)
+        pr = torch.softmax(torch.randn(B, R1.size(0), device=x_t.device), 1)
+        scale = 1.0 / R0.size(1) ** 0.5
+        ms = _timed(lambda: ops.nt_gemm(xf, R0t, (pr, R1, scale)))
+        ms_b = _timed(lambda: ops.nt_gemm(pr.new_empty(B, R0.size(1)).normal_(), R0))
         out["cdan_random_layer_gemm"] = {
             "ms": ms, "TFLOPps": 2.0 * B * C * L * R0.size(1) / (ms * 1e-3) / 1e12,
             "algorithmic_GBps": 4.0 * (R0.numel() + xf.numel() + B * R0.size(1)) / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
-            "counters": "profiles/r02_randlayer_hbm_traffic.csv, profiles/r02_randlayer_mfma_busy.csv",
-            "note": "256 x 25600 x 1024 on the conv engine (split-bf16 MFMA, K split with fp32 atomics); the 105 MB fixed "
-                    "matrix is read once: HBM-bound at small B"}
+            "matrix_GBps": 4.0 * R0.numel() / (ms * 1e-3) / 1e9, "data_gradient_ms": ms_b,
+            "counters": "profiles/r03_north_star_micro_hbm_traffic.csv, profiles/r03_north_star_micro_mfma_busy.csv",
+            "note": "RandomLayer.forward as ONE GEMM: 256 x 25600 x 1024 on the time-as-k kernel (fst_nt_gemm: split-bf16 MFMA, both "
+                    "operands row-major with K contiguous, the 105 MB fixed matrix read once by the LDS-DMA ring, K split into 32 "
+                    "partial slabs added in a fixed order - no atomics) with the class-side product, the 1/sqrt(1024) scale and the "
+                    "Hadamard product in the reduce epilogue; data_gradient_ms: dy x R0 (256 x 1024 x 25600, no K split)"}
     return out
 
 

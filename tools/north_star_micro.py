@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The three kernels BASELINE.json's north_star names besides the step rate, alone, at the metric batch (B=256, L=512):
 the omni-scale Conv1d sweep (OS_CNN_res forward, train-mode BatchNorm), the CPC cross-Gram (CPCNceFn forward) and the
-CDAN random-layer GEMM (_fixed_matmul).  Run under rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES
+CDAN random-layer GEMM (ops.nt_gemm with RandomLayer's epilogue, and its data gradient).  Run under rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES
 passes) for the counter evidence in profiles/r02_*; prints HIP-event timings otherwise."""
 import os, sys
 import torch
@@ -41,5 +41,10 @@ with torch.no_grad():
     macs = 964 + 216900 + 16875 + 50
     timed("omni_scale_fe_forward", lambda: fe(x), 2.0 * macs * B * L, 4.0 * (1 + C) * B * L)
     timed("cpc_cross_gram", lambda: ops.CPCNceFn.apply(feat, pred, 7, T), 2.0 * T * B * B * C, 4.0 * (B * C * T + T * B * C))
-    timed("cdan_random_layer_gemm", lambda: ops._fixed_matmul(xf, R0, B, C * L, 1024), 2.0 * B * C * L * 1024,
+    R0t = R0.t().contiguous()
+    R1 = torch.randn(4, 1024, device=dev)
+    pr = torch.softmax(torch.randn(B, 4, device=dev), 1)
+    dyr = torch.randn(B, 1024, device=dev)
+    timed("cdan_random_layer_gemm", lambda: ops.nt_gemm(xf, R0t, (pr, R1, 1.0 / 32.0)), 2.0 * B * C * L * 1024,
           4.0 * (R0.numel() + xf.numel() + B * 1024))
+    timed("cdan_random_layer_dgrad", lambda: ops.nt_gemm(dyr, R0), 2.0 * B * C * L * 1024, 4.0 * (R0.numel() + xf.numel() + B * 1024))
