@@ -573,7 +573,7 @@ extern "C" int64_t fst_wn_wgrad_workspace_floats(int kind, int B, int L, int n, 
   return (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2);
 }
 
-static int ww_launch(WwParams& p, int KT, void* stream) {
+static int ww_launch(WwParams& p, int KT, void* stream, bool reduce = true) {
   static const int exp_env = getenv("FST_WW_EXP") ? atoi(getenv("FST_WW_EXP")) : 0;
   p.exp = exp_env;
   const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + (size_t)WW_NX * p.RX * 128;
@@ -591,6 +591,7 @@ static int ww_launch(WwParams& p, int KT, void* stream) {
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_wn_wgrad")) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
+  if (!reduce) return 0;
   hipLaunchKernelGGL(wn_wgrad_reduce_kernel, dim3((unsigned)((p.Kcols + 255) / 256), (unsigned)p.M), dim3(256), 0, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
@@ -710,5 +711,9 @@ extern "C" int fst_nt_gemm(const float* A, const float* Bm, float* C, float* wor
   p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
   p.w[0] = C; p.w[1] = nullptr;
   p.epi_p = epi_p; p.epi_r1 = epi_r1; p.epi_ncls = epi_ncls; p.epi_scale = epi_scale; p.epi_raw = epi_raw;
-  return ww_launch(p, 2, stream);
+  // one K slice of all 256 rows whose slab [256][n_groups·128] IS the output [M][N] (the data gradient of the random layer):
+  // the workgroups store straight into C, no second pass
+  const bool direct = p.ksplit == 1 && M == WW_MROWS && p.Kcols == N && !epi_p;
+  if (direct) p.slab = C;
+  return ww_launch(p, 2, stream, !direct);
 }
