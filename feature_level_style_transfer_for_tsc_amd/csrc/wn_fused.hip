@@ -679,10 +679,14 @@ extern "C" int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, i
 // GEMM 3 has M = n (4 row blocks), K = 2n (n on the last layer): 12 MFMAs per 16-deep stage against 16 KiB of operand
 // fill, and its inputs and outputs (d_a_next, d_out, t, s read once; dg written once) are 378 MB per layer — HBM-bound by a
 // factor seven, so the kernel is shaped for streaming: small workgroups (one batch element × 128 samples, 50 KB of LDS,
-// three per CU), the t,s tiles of the first row block prefetched before the GEMM, the next block's while one is gated.
+// two per CU — WN_BWD_OCC), the t,s tiles of the first row block prefetched before the GEMM, the next block's while one is gated.
 // Image: S3 = 2·CH (CH on the last layer) stages × 4 row blocks × (1 KiB hi + 1 KiB lo), then 16 B of zeros; stage (src, c):
 // lane l holds W_rs[src·n + 16c + 8(l>>5) + j][blk·32 + (l&31)] — W_rs transposed, rows = acts channels.
 // ------------------------------------------------------------------------------------------------
+#ifndef WN_BWD_OCC
+#define WN_BWD_OCC 2                                 // workgroups per CU the register budget is set for: 1024 tiles of the metric shape = two full
+                                                     // rounds of 512 slots (three per CU: 1.33 rounds, 77 -> 70 us; and no scratch)
+#endif
 #define WN_BW_NB 4                                   // column blocks of a B row group (no tap shift: no spill block)
 #define WN_BW_GS (WN_BW_NB * 1024 + 128)
 #define WN_BW_A (4 * 2048)
@@ -741,7 +745,7 @@ struct WnBwdParams {
   int B, L, n, last, CH, tiles_per_seq, n_wg;
 };
 
-__global__ __launch_bounds__(256, 3) void wn_layer_bwd_kernel(WnBwdParams p) {
+__global__ __launch_bounds__(256, WN_BWD_OCC) void wn_layer_bwd_kernel(WnBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const ldsb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x, lane = tid & 63;
