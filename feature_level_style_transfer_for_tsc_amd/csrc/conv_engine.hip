@@ -1780,7 +1780,7 @@ __global__ __launch_bounds__(256) void pack_bf3_kernel(PackParams p, const int32
   const int32_t* c = pv.chunk + 4 * q;
   const int lo = e[0], hi = e[1];
   const int MB = pv.MB, s = c[0];
-  if (blockIdx.y == 0 && threadIdx.x < 4)            // the 16-byte zero block behind the image (masked LDS-DMA pieces read it)
+  if (blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x < 4)            // the 16-byte zero block behind the image (masked LDS-DMA pieces read it)
     p.a[(long long)pv.n_stages * MB * 512 + threadIdx.x] = 0.f;
   if (hi <= lo) return;
   const int total = (hi - lo) * MB * 64;
@@ -1832,7 +1832,16 @@ static int launch_pack(const int32_t* plan_dev, const int32_t* plan_host, int pl
   if (bf3) {
     FST_REQUIRE(pv.chunk_cap <= PIPE_C, "%s: the split-bf16 image needs chunks of <= %d channels (got %d)", who, PIPE_C,
                 pv.chunk_cap);
-    hipLaunchKernelGGL(pack_bf3_kernel, dim3(1, (unsigned)(pv.n_chunks * (p0.g_end - p0.g_begin))), dim3(256), 0,
+    // one thread per (tap, 32-row block, lane) of the entry with the most taps; entries with fewer leave some workgroups idle
+    long long bxb = 0;
+    for (int gq = p0.g_begin * pv.n_chunks; gq < p0.g_end * pv.n_chunks; ++gq) {
+      const int32_t* e = pv.mg + 4 * gq;
+      const long long t = (long long)(e[1] > e[0] ? e[1] - e[0] : 0) * pv.MB * 64;
+      bxb = bxb > t ? bxb : t;
+    }
+    bxb = (bxb + 255) / 256;
+    bxb = bxb < 1 ? 1 : (bxb > 64 ? 64 : bxb);
+    hipLaunchKernelGGL(pack_bf3_kernel, dim3((unsigned)bxb, (unsigned)(pv.n_chunks * (p0.g_end - p0.g_begin))), dim3(256), 0,
                        (hipStream_t)stream, p, plan_dev);
   } else {
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)bx, (unsigned)(pv.n_chunks * (p0.g_end - p0.g_begin))), dim3(256), 0,
