@@ -717,3 +717,76 @@ extern "C" int fst_nt_gemm(const float* A, const float* Bm, float* C, float* wor
   if (direct) p.slab = C;
   return ww_launch(p, 2, stream, !direct);
 }
+
+// ------------------------------------------------------------------------------------------------ few-tap conv weight gradient
+// dW[m][c][τ] = Σ_{b,t} dy[b][m][t]·x[b][c][t + τ·dil − pad_left] for a conv with at most four taps (a tap = one k-row segment with
+// its own shift) — the dense (Q1) gradient of the shared omni-scale block's last layer (225 → 50 channels, two taps), which the
+// generic item-table kernel ran at 29 TFLOP/s.  Tap shifts that are not multiples of 4 samples must be within ±3 and need 16
+// readable bytes either side of x (x_slack), as fst_wn_wgrad_in.
+extern "C" int fst_tap_wgrad_ok(int B, int L, int M, int C, int ntaps, int dil, int pad_left) {
+  if (!(B > 0 && L > 0 && L % WW_TT == 0 && M > 0 && M <= WW_MROWS && C > 0 && ntaps >= 1 && ntaps <= 4 && dil > 0)) return 0;
+  if (((long long)ntaps * C + 31) / 32 > 18) return 0;                       // (k-row blocks of all groups: LDS geometry as above)
+  int need_slack = 0;
+  for (int tap = 0; tap < ntaps; ++tap) {
+    const int sh = tap * dil - pad_left;
+    if (sh % 4 != 0) {
+      if (sh <= -4 || sh >= 4) return 0;
+      need_slack = 1;
+    }
+  }
+  return need_slack ? 2 : 1;
+}
+
+static void tap_geometry(int B, int L, int M, int C, int ntaps, WwParams* p) {
+  p->M = M; p->K = ntaps * C; p->K_main = p->K; p->n_extra = 0;
+  p->xr = 192;
+  p->n_groups = ((p->K + 31) / 32 + 5) / 6;
+  p->mul = 0;
+  p->RX = p->xr;
+  p->Kcols = p->n_groups * p->xr;
+  p->B = B; p->L = L;
+  p->tiles_per_seq = L / WW_TT;
+  p->n_tiles = B * p->tiles_per_seq;
+  const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
+  int ks = cus / p->n_groups;
+  if (ks > p->n_tiles) ks = p->n_tiles;
+  if (ks < 1) ks = 1;
+  p->ksplit = ks;
+  p->n_sets = 1;
+}
+
+extern "C" int64_t fst_tap_wgrad_workspace_floats(int B, int L, int M, int C, int ntaps) {
+  if (!fst_tap_wgrad_ok(B, L, M, C, ntaps, 4, 0)) return -1;
+  WwParams p = {};
+  tap_geometry(B, L, M, C, ntaps, &p);
+  return (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2);
+}
+
+extern "C" int fst_tap_wgrad(const float* dy, const float* x, float* dw, float* workspace, int64_t workspace_floats, int B, int L, int M,
+                             int C, int ntaps, int dil, int pad_left, int x_slack, int64_t numel_dy, int64_t numel_x, void* stream) {
+  FST_REQUIRE(dy && x && dw && workspace, "fst_tap_wgrad: null operand");
+  const int served = fst_tap_wgrad_ok(B, L, M, C, ntaps, dil, pad_left);
+  FST_REQUIRE(served == 1 || (served == 2 && x_slack), "fst_tap_wgrad: unsupported shape B=%d L=%d M=%d C=%d ntaps=%d dil=%d pad_left=%d "
+              "(needs L %% 32 == 0, M <= 256, at most 4 taps, tap shifts multiples of 4 or — with 16 readable bytes either side of x — "
+              "within 3 samples)", B, L, M, C, ntaps, dil, pad_left);
+  FST_REQUIRE((long long)B * M * L == (long long)numel_dy && (long long)B * C * L == (long long)numel_x,
+              "fst_tap_wgrad: B*M*L / B*C*L do not match the element counts %lld / %lld", (long long)numel_dy, (long long)numel_x);
+  FST_REQUIRE(ww_al16(dy) && ww_al16(x) && ww_al16(workspace), "fst_tap_wgrad: operands must be 16-byte aligned");
+  WwParams p = {};
+  tap_geometry(B, L, M, C, ntaps, &p);
+  FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * (p.Kcols + 2), "fst_tap_wgrad: workspace of %lld floats is too small",
+              (long long)workspace_floats);
+  p.n_dy = 1;
+  p.dy[0] = {{dy, nullptr, nullptr}, (long long)M * L, 0, M, 0, 0, 0, 0, 0};
+  p.n_x = ntaps;
+  p.misaligned = 0;
+  for (int tap = 0; tap < ntaps; ++tap) {
+    const int sh = tap * dil - pad_left;
+    p.x[tap] = {{x, nullptr, nullptr}, (long long)C * L, 0, C, sh, 0, tap, ntaps, C * ntaps};    // dW[m][c][tap] at m·C·ntaps + c·ntaps + tap
+    if (sh % 4 != 0) p.misaligned = 1;
+  }
+  p.slab = workspace;
+  p.slab_extra = workspace + (long long)p.ksplit * WW_MROWS * p.Kcols;
+  p.w[0] = dw; p.w[1] = nullptr;
+  return ww_launch(p, 3, stream);
+}

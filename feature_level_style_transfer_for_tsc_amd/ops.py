@@ -330,6 +330,19 @@ class ConvSpec:
         self._plans: Dict[Tuple[str, int], Plan] = {}
         self.mb = 1 if self.row_live is not None and ntaps > 2 else pick_mb(M)
 
+    def tap_wgrad_ok(self, B: int, L: int, x0: Tensor, dy: Tensor) -> bool:
+        """Whether ``tap_wgrad`` (csrc/wn_wgrad.hip) serves this conv's DENSE weight gradient: no side input, every tap wanted (a dense
+        plan, or no tap mask at all), at most four taps, split-bf16 mode, contiguous operands — and slack around x when a tap is shifted
+        by 1-3 samples.  Worth it only for layers the item-table kernel runs badly (many channels, few taps)."""
+        if self.C1 or MATH != "bf16x3" or not (self.dense_dw or self.row_live is None) or self.ntaps < 2 or self.C0 < 64:
+            return False
+        if os.environ.get("FST_TAP_WGRAD", "1") == "0" or not (x0.is_contiguous() and dy.is_contiguous()):
+            return False
+        if x0.data_ptr() % 16 or dy.data_ptr() % 16:
+            return False
+        served = _lib.load().fst_tap_wgrad_ok(B, L, self.M, self.C0, self.ntaps, self.dil, self.pad_left)
+        return served == 1 or (served == 2 and has_slack(x0))
+
     # ---- heuristics
     def _halo(self) -> int:
         return (self.ntaps - 1) * self.dil
@@ -513,6 +526,11 @@ class ConvSpec:
         ``out0`` / ``out1``: contiguous [M, C0, ntaps] / [M, C1, 1] tensors (segments of a flat gradient, zero-filled when
         the plan does not write every element) that receive the gradients in place."""
         B, L = x0.size(0), x0.size(2)
+        if x1 is None and dy2 is None and msplit is None and not x0_mul_off and self.tap_wgrad_ok(B, L, x0, dy):
+            # dense gradient of a conv with a few taps: the time-as-k kernel (each tap a k-row segment with its own shift)
+            dw0 = out0 if out0 is not None else torch.empty(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
+            tap_wgrad(dy, x0, dw0, self.M, self.C0, self.ntaps, self.dil, self.pad_left)
+            return dw0, None
         plan = self.wg_plan()
         n_wg = max(1, len(plan.items()) // 4)
         da = conv_wgrad(plan, x0, x1, dy, dy2, self.M if msplit is None else msplit, B, L, self.M,
@@ -691,7 +709,8 @@ class BNActFn(torch.autograd.Function):
         y = y.contiguous()
         B, C, L = y.shape
         stats = _bn_stats(y, gamma, beta, rmean, rvar, training, eps, momentum)
-        out = torch.empty_like(y)
+        # (16 bytes of slack either side: the next conv's few-tap weight gradient may read its taps through shifted 16-byte pieces)
+        out = empty_with_slack(B, C, L, y.device)
         check(lib.fst_bn_apply(ptr(y), ptr(stats), None, None, ptr(out), B, C, L, int(relu), _same_numel(y, out), stream_ptr()),
               "fst_bn_apply")
         ctx.save_for_backward(y, out, stats)
@@ -853,6 +872,25 @@ def wn_wgrad_rs(d_a, d_out, ts, dw_rs: Tensor, last: bool, n: int) -> None:
                               int(last), B, L, n, numel, stream_ptr()), "fst_wn_wgrad_rs")
     if t0 is not None:
         KERNEL_TIMER.end("wn_wgrad_kernel<2, 2> bf3", t0, 2.0 * ns * B * L * M * n, 4.0 * ns * B * L * (M + 2 * n))
+
+
+def tap_wgrad(dy: Tensor, x: Tensor, dw: Tensor, M: int, C: int, ntaps: int, dil: int, pad_left: int) -> None:
+    """dw [M, C, ntaps] = Σ_{b,t} dy[b, m, t]·x[b, c, t + τ·dil − pad_left] — written in place (fst_tap_wgrad: time-as-k kernel)."""
+    lib = _lib.load()
+    B, _, L = dy.shape
+    if tuple(dy.shape) != (B, M, L) or tuple(x.shape) != (B, C, L) or not (dy.is_contiguous() and x.is_contiguous()):
+        raise ValueError(f"tap_wgrad: dy {tuple(dy.shape)} / x {tuple(x.shape)} must be contiguous [B, {M}, L] / [B, {C}, L]")
+    if tuple(dw.shape) != (M, C, ntaps) or not dw.is_contiguous() or dw.dtype != torch.float32:
+        raise ValueError(f"tap_wgrad: gradient target of shape {tuple(dw.shape)}, expected contiguous {(M, C, ntaps)}")
+    ws_n = lib.fst_tap_wgrad_workspace_floats(B, L, M, C, ntaps)
+    if ws_n <= 0:
+        raise ValueError(f"tap_wgrad: unsupported shape B={B} L={L} M={M} C={C} ntaps={ntaps}")
+    ws = torch.empty(ws_n, device=dy.device, dtype=torch.float32)
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_tap_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(ws), ws_n, B, L, M, C, ntaps, dil, pad_left, int(has_slack(x)), dy.numel(),
+                            x.numel(), stream_ptr()), "fst_tap_wgrad")
+    if t0 is not None:
+        KERNEL_TIMER.end("tap_wgrad (wn_wgrad_kernel<2, 3>) bf3", t0, 2.0 * B * L * M * C * ntaps, 4.0 * B * L * (M + C))
 
 
 def _ptr_sets(ts: Sequence[Tensor]):

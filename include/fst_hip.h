@@ -290,6 +290,17 @@ int fst_nt_gemm(const float* A, const float* Bm, float* C, float* workspace, int
                 const float* epi_p /* [M][ncls] */, const float* epi_r1 /* [ncls][N] */, int epi_ncls, float epi_scale,
                 float* epi_raw /* [M][N] */, void* stream);
 
+/* dW[m][c][τ] = Σ_{b,t} dy[b][m][t]·x[b][c][t + τ·dil − pad_left]: the dense weight gradient of a conv with at most four taps on the
+ * time-as-k kernel (each tap = one k-row segment with its own shift) — the Q1 gradient of the shared omni-scale block's last layer
+ * (/root/reference/OS_CNN/OS_CNN.py:67-71, 225 → 50 channels, two taps; train_and_test.py:685-690 reads it).  fst_tap_wgrad_ok: 1 served,
+ * 2 served provided 16 bytes either side of x are readable (x_slack: a tap shift that is not a multiple of 4 samples, within ±3),
+ * 0 not served (M > 256, L % 32 != 0, more than 4 taps, larger misaligned shifts): the caller uses fst_conv_wgrad. */
+int fst_tap_wgrad_ok(int B, int L, int M, int C, int ntaps, int dil, int pad_left);
+int64_t fst_tap_wgrad_workspace_floats(int B, int L, int M, int C, int ntaps);
+int fst_tap_wgrad(const float* dy, const float* x, float* dw /* [M][C][ntaps], written */, float* workspace, int64_t workspace_floats,
+                  int B, int L, int M, int C, int ntaps, int dil, int pad_left, int x_slack, int64_t numel_dy, int64_t numel_x,
+                  void* stream);
+
 /* NoiseTransfer (/root/reference/widgets.py:150-167): new_t = avg_t + r_t·mean_b(z_t), new_s likewise, dist = new_t − new_s,
  * learned = selu(W·dist + bias) (unbatched 1x1 conv over the [C, L] map), out[b] = learned + z_s[b].
  *   fst_batch_sum            part[z][s][i] = Σ_{b in slice s} x_z[b][i] (z < 2 tensors, x1 may be NULL; S contiguous slices of the

@@ -667,3 +667,26 @@ def test_random_layer_fused_vs_composition(Bq, D, O, ncls):
     assert_close(out, want, 2e-5, "random layer out")
     assert_close(gx, wx, 2e-5, "random layer dx")
     assert_close(gp, wp, 2e-5, "random layer dp")
+
+
+@pytest.mark.parametrize("M,C,ntaps,dil,pad,Bq,L", [(50, 225, 2, 1, 0, 256, 512), (50, 225, 2, 1, 0, 3, 64), (33, 70, 3, 4, 4, 2, 96),
+                                                    (8, 64, 4, 1, 1, 2, 32), (256, 130, 3, 1, 1, 2, 64)])
+def test_few_tap_dense_weight_gradient_vs_fp64(M, C, ntaps, dil, pad, Bq, L):
+    """fst_tap_wgrad (the dense gradient of a conv with 2-4 taps on the time-as-k kernel; ConvSpec.grad_w routes the shared
+    omni-scale block's last layer there) against an fp64 einsum, x between NaN-poisoned guard bands; bit-identical twice."""
+    g = torch.Generator(device=DEV).manual_seed(M + C + L)
+    x = ops.empty_with_slack(Bq, C, L, DEV)
+    x.untyped_storage().copy_(torch.full((Bq * C * L + 8,), float("nan")).untyped_storage())
+    x.copy_(torch.randn(Bq, C, L, generator=g, device=DEV))
+    dy = torch.randn(Bq, M, L, generator=g, device=DEV)
+    spec = ops.ConvSpec(M, C, ntaps, dil, pad)
+    assert spec.tap_wgrad_ok(Bq, L, x, dy)
+    dw, _ = spec.grad_w(x, None, dy)
+    halo = (ntaps - 1) * dil
+    xp = F.pad(x.double(), (pad, halo - pad))
+    want = torch.stack([torch.einsum("bmt,bct->mc", dy.double(), xp[:, :, k * dil: k * dil + L]) for k in range(ntaps)], dim=2)
+    assert_close(dw, want, 1e-4, "few-tap dW")
+    again, _ = spec.grad_w(x, None, dy)
+    assert torch.equal(dw, again)
+    if any((k * dil - pad) % 4 for k in range(ntaps)):
+        assert not spec.tap_wgrad_ok(Bq, L, x.clone(), dy)                      # no slack: the generic kernel serves it
