@@ -336,7 +336,9 @@ class ConvSpec:
         by 1-3 samples.  Worth it only for layers the item-table kernel runs badly (many channels, few taps)."""
         if self.C1 or MATH != "bf16x3" or not (self.dense_dw or self.row_live is None) or self.ntaps < 2 or self.C0 < 64:
             return False
-        if os.environ.get("FST_TAP_WGRAD", "1") == "0" or not (x0.is_contiguous() and dy.is_contiguous()):
+        # OFF by default: measured at the one layer it fits (225 → 50 channels, two taps, B=256, L=512) it takes 128 µs against the
+        # item-table kernel's 85 — with 50 output rows the 256-row dy ring is four fifths padding.  FST_TAP_WGRAD=1 enables it.
+        if os.environ.get("FST_TAP_WGRAD", "0") != "1" or not (x0.is_contiguous() and dy.is_contiguous()):
             return False
         if x0.data_ptr() % 16 or dy.data_ptr() % 16:
             return False
@@ -709,8 +711,7 @@ class BNActFn(torch.autograd.Function):
         y = y.contiguous()
         B, C, L = y.shape
         stats = _bn_stats(y, gamma, beta, rmean, rvar, training, eps, momentum)
-        # (16 bytes of slack either side: the next conv's few-tap weight gradient may read its taps through shifted 16-byte pieces)
-        out = empty_with_slack(B, C, L, y.device)
+        out = torch.empty_like(y)
         check(lib.fst_bn_apply(ptr(y), ptr(stats), None, None, ptr(out), B, C, L, int(relu), _same_numel(y, out), stream_ptr()),
               "fst_bn_apply")
         ctx.save_for_backward(y, out, stats)

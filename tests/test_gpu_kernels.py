@@ -671,9 +671,10 @@ def test_random_layer_fused_vs_composition(Bq, D, O, ncls):
 
 @pytest.mark.parametrize("M,C,ntaps,dil,pad,Bq,L", [(50, 225, 2, 1, 0, 256, 512), (50, 225, 2, 1, 0, 3, 64), (33, 70, 3, 4, 4, 2, 96),
                                                     (8, 64, 4, 1, 1, 2, 32), (256, 130, 3, 1, 1, 2, 64)])
-def test_few_tap_dense_weight_gradient_vs_fp64(M, C, ntaps, dil, pad, Bq, L):
+def test_few_tap_dense_weight_gradient_vs_fp64(M, C, ntaps, dil, pad, Bq, L, monkeypatch):
     """fst_tap_wgrad (the dense gradient of a conv with 2-4 taps on the time-as-k kernel; ConvSpec.grad_w routes the shared
     omni-scale block's last layer there) against an fp64 einsum, x between NaN-poisoned guard bands; bit-identical twice."""
+    monkeypatch.setenv("FST_TAP_WGRAD", "1")                    # (off by default: slower than the item-table kernel where it fits)
     g = torch.Generator(device=DEV).manual_seed(M + C + L)
     x = ops.empty_with_slack(Bq, C, L, DEV)
     x.untyped_storage().copy_(torch.full((Bq * C * L + 8,), float("nan")).untyped_storage())
