@@ -66,6 +66,9 @@ _SIGNATURES = {
     "fst_tap_wgrad_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "fst_tap_wgrad_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "fst_tap_wgrad": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "fst_dense_tap_wgrad_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "fst_dense_tap_wgrad_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "fst_dense_tap_wgrad": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "fst_relu_bwd": (c_int, [_P, _P, _P, c_int64, c_void_p]),
     "fst_batch_sum": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_void_p]),
     "fst_noise_transfer_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_void_p]),

@@ -790,3 +790,309 @@ extern "C" int fst_tap_wgrad(const float* dy, const float* x, float* dw, float* 
   p.w[0] = dw; p.w[1] = nullptr;
   return ww_launch(p, 3, stream);
 }
+
+// ================================================================================================ dense many-tap weight gradient
+// dW[m][c][k] = Σ_{b,t} dy[b][m][t]·x[b][c][t + k − pad]  for EVERY tap k < K <= 96 of an omni-scale layer (the Q1 gradient of the
+// shared OS_block, /root/reference/OS_CNN/OS_CNN.py:67-71 + train_and_test.py:685-690: the reference convolves the dense Kmax kernel,
+// so autograd's weight gradient is dense and GradNorm's norms run over it).  Time is the MFMA reduction index as above, but the
+// K k-rows of a channel are the SAME row of x at K consecutive shifts: one 160-sample window of the channel is staged per stage
+// (one LDS-DMA instruction, always 16-byte aligned) and the split pass writes it out EIGHT times, as bf16 hi / lo copies shifted
+// by 0..7 samples.  The B fragment of k-row "shift s" at samples t.. t+7 is then the 16-byte aligned unit ⌊o/8⌋ of copy o mod 8
+// (o = s + t − window start): one ds_read_b128 per part, no per-shift staging — the item-table kernel stages every (tap, channel)
+// row on its own and reaches 0.23 of the matrix peak on the 225 × 25 × 89 layer.
+// A workgroup = all M rows × TZ_CW channels × 3 blocks of 32 shifts; waves 4 (row pairs) × 2 (channels), 2 × 3 tiles each.
+#define TZ_CW 2
+#define TZ_CPB 288                                         // bytes per shifted copy: 16 units of 16 B + 32 (16-lane groups then hit all banks)
+#define TZ_XRAW 1024                                       // bytes per staged raw window (40 of 64 pieces used)
+#define TZ_COPIES (TZ_CW * 2 * 8 * TZ_CPB)
+
+struct TzParams {
+  const float* dy;      // [B][M][L]
+  const float* x;       // [B][C][L]
+  float* slab;          // [ksplit][256][Kcols]
+  float* dw;            // [M][C][K]
+  int B, L, M, C, K, P4;        // P4: the window of stage t0 starts at sample t0 − P4 (pad rounded up to 4, plus 4)
+  int off0;                     // P4 − pad: window offset of (shift 0, sample t0)
+  int n_groups, ksplit, tiles_per_seq, n_tiles, Kcols;
+};
+
+__device__ __forceinline__ float tz_lds_read4(const char* p) {
+  float v;
+  const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void tz_wait_at_most() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
+  extern __shared__ __attribute__((aligned(16))) char tz_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave_s >> 1, wk = wave_s & 1;
+  const int g = blockIdx.y, L = p.L;
+  constexpr int dslot_bytes = WW_MROWS * 128;
+  char* const xraw = tz_lds + WW_ND * dslot_bytes;          // [2 slots][TZ_CW][TZ_XRAW]
+  char* const copies = xraw + 2 * TZ_CW * TZ_XRAW;          // [hi | lo][TZ_CW][8 copies][TZ_CPB]
+  const char* const zero16 = reinterpret_cast<const char*>(ww_zero16);
+
+  // ---- dy rows: ⌈M/8⌉ LDS-DMA instructions per stage (8 rows each), instruction i = wave + 8k
+  const int nd = (p.M + 7) >> 3;
+  const int my_nd = nd > wave_s ? (nd - wave_s + 7) >> 3 : 0;
+  WwSrc dsrc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = wave_s + 8 * k;
+    const int r = ww_dma_row(i, lane), q = (lane ^ r) & 7;
+    dsrc[k].p = r < p.M ? p.dy + ((long long)r * L + 4 * q) : nullptr;
+    dsrc[k].bs = 0; dsrc[k].t = 4 * q;
+  }
+  // ---- the window of channel 2g + wave (waves 0, 1): piece `lane` (< 40) of the 160 samples from t0 − P4
+  const int my_ch = TZ_CW * g + wave_s;
+  const float* const xrow = (wave_s < TZ_CW && my_ch < p.C && lane < 40) ? p.x + ((long long)my_ch * L + 4 * lane) : nullptr;
+  const long long dy_bs = (long long)p.M * L, x_bs = (long long)p.C * L;
+  __builtin_amdgcn_s_waitcnt(0x0F70);                      // (see wn_wgrad_kernel: per-lane selections of kernel arguments)
+
+  auto tile_bt = [&](int tile, int& b, int& t0) {
+    b = tile / p.tiles_per_seq;
+    t0 = (tile - b * p.tiles_per_seq) * WW_TT;
+  };
+  auto issue_dy1 = [&](int k, int b, int t0, int slot) {
+    if (k >= my_nd) return;                                // wave-uniform
+    const bool ok = dsrc[k].p != nullptr;
+    const char* src = ok ? reinterpret_cast<const char*>(dsrc[k].p + (b * dy_bs + t0)) : zero16;
+    ww_dma16(src, tz_lds + slot * dslot_bytes + (wave_s + 8 * k) * 1024);
+  };
+  auto issue_x1 = [&](int b, int t0, int slot) {
+    if (wave_s >= TZ_CW) return;                           // wave-uniform
+    const int t = t0 - p.P4 + 4 * lane;                    // (multiples of 4: a piece is inside the sequence or outside it)
+    const bool ok = xrow != nullptr && t >= 0 && t < L;
+    const char* src = ok ? reinterpret_cast<const char*>(xrow + (b * x_bs + t0 - p.P4)) : zero16;
+    ww_dma16(src, xraw + (slot * TZ_CW + wave_s) * TZ_XRAW);
+  };
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int tile_begin = (int)(((long long)blockIdx.x * p.n_tiles) / p.ksplit);
+  const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.n_tiles) / p.ksplit);
+  const int m_blocks = (p.M + 31) >> 5;
+  const int k_blocks = (p.K + 31) >> 5;                    // live 32-shift blocks (<= 3)
+  const bool ch_live = TZ_CW * g + wk < p.C;
+
+  // A fragments: as in wn_wgrad_kernel (row block·32 + l31, unit 2·ks + half: hi = first piece, lo = second)
+  const int row_l = (l31 ^ ((l31 >> 3) & 1)) << 7;
+  const int sw = l31 & 7;
+  int pc[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    pc[ks][0] = (((4 * ks + 2 * half) ^ sw) & 7) << 4;
+    pc[ks][1] = (((4 * ks + 2 * half + 1) ^ sw) & 7) << 4;
+  }
+  const int a_off = ((wm * 2 * 32) << 7) + row_l;
+  // B fragments: shift s = 32·sb + l31 at samples 16·ks + 8·half + 0..7 → window offset o = off0 + s + 16·ks + 8·half: copy o & 7
+  // (the same for every ks, sb), unit o >> 3
+  const int o0 = p.off0 + l31 + 8 * half;
+  const int b_off = wk * (8 * TZ_CPB) + (o0 & 7) * TZ_CPB + ((o0 >> 3) << 4);
+
+  const int n_st = tile_end - tile_begin;
+  {
+    int b, t0;
+    if (n_st > 0) {
+      tile_bt(tile_begin, b, t0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) issue_dy1(k, b, t0, 0);
+      issue_x1(b, t0, 0);
+    }
+    if (n_st > 1) {
+      tile_bt(tile_begin + 1, b, t0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) issue_dy1(k, b, t0, 1);
+    }
+  }
+  int dslot = 0, xslot = 0;
+  for (int c = 0; c < n_st; ++c) {
+    // everything but the dy pieces of stage c + 1 (this wave's my_nd most recent issues) has landed
+    if (c + 1 >= n_st || my_nd == 0) tz_wait_at_most<0>();
+    else if (my_nd == 1) tz_wait_at_most<1>();
+    else if (my_nd == 2) tz_wait_at_most<2>();
+    else if (my_nd == 3) tz_wait_at_most<3>();
+    else tz_wait_at_most<4>();
+    __builtin_amdgcn_s_barrier();
+    const bool have_x = c + 1 < n_st, have_dy = c + 2 < n_st;
+    int nb = 0, nt0 = 0, db = 0, dt0 = 0;
+    if (have_x) tile_bt(tile_begin + c + 1, nb, nt0);
+    if (have_dy) tile_bt(tile_begin + c + 2, db, dt0);
+    const int x_next = xslot ^ 1, d_next = dslot >= 1 ? dslot - 1 : 2;
+    auto issue_pos = [&](int pos) {                        // pos 0: the window piece; 1..4: dy pieces (issue order as counted above)
+      if (pos == 0) { if (have_x) issue_x1(nb, nt0, x_next); }
+      else if (pos <= 4) { if (have_dy) issue_dy1(pos - 1, db, dt0, d_next); }
+    };
+    // ---- split pass.  dy: in place (thread t: units t and t + 512 = rows t>>2 and 128 + (t>>2), unit t&3).  x: thread t < 256 builds
+    // unit q = t & 15 of copy r = (t >> 4) & 7 of channel t >> 7: window samples 8q + r .. 8q + r + 7
+    {
+      char* const dw = tz_lds + dslot * dslot_bytes;
+      const int u = tid & 3, r0 = tid >> 2;
+      ww_f32x4 d[2][2];
+      char* da[2][2];
+      const int dy_rows = nd << 3;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = r0 + 128 * i;
+        da[i][0] = dw + ww_lds_off(r, 2 * u); da[i][1] = dw + ww_lds_off(r, 2 * u + 1);
+        if (r < dy_rows) { d[i][0] = ww_lds_read16(da[i][0]); d[i][1] = ww_lds_read16(da[i][1]); }
+      }
+      float xv[8];
+      const int xc = tid >> 7, xr = (tid >> 4) & 7, xq = tid & 15;
+      if (tid < 128 * TZ_CW) {
+        const char* src = xraw + (xslot * TZ_CW + xc) * TZ_XRAW + (8 * xq + xr) * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = tz_lds_read4(src + 4 * j);
+      }
+      ww_lds_wait();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = r0 + 128 * i;
+        if (r < dy_rows) {
+          ww_u32x4 h4, l4;
+          ww_split8u(d[i][0], d[i][1], h4, l4);
+          ww_lds_write16(da[i][0], h4); ww_lds_write16(da[i][1], l4);
+        }
+      }
+      if (tid < 128 * TZ_CW) {
+        ww_u32x4 h4, l4;
+        unsigned hh, ll;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ww_split_pair(xv[2 * j], xv[2 * j + 1], hh, ll); h4[j] = hh; l4[j] = ll; }
+        char* dst = copies + xc * (8 * TZ_CPB) + xr * TZ_CPB + (xq << 4);
+        ww_lds_write16(dst, h4);
+        ww_lds_write16(dst + TZ_CW * 8 * TZ_CPB, l4);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    // ---- multiply
+    const char* const dsl = tz_lds + dslot * dslot_bytes;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      ww_f32x4 araw[2][2], braw[3][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const char* ap = dsl + a_off + ((i * 32) << 7);
+        araw[i][0] = ww_lds_read16(ap + pc[ks][0]);
+        araw[i][1] = ww_lds_read16(ap + pc[ks][1]);
+      }
+#pragma unroll
+      for (int sb = 0; sb < 3; ++sb) {
+        const char* bp = copies + b_off + ((2 * ks + 4 * sb) << 4);
+        braw[sb][0] = ww_lds_read16(bp);
+        braw[sb][1] = ww_lds_read16(bp + TZ_CW * 8 * TZ_CPB);
+      }
+      ww_lds_wait();
+      issue_pos(3 * ks);
+#pragma unroll
+      for (int sb = 0; sb < 3; ++sb) {
+        if (sb < k_blocks && ch_live) {                    // wave-uniform
+          const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[sb][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[sb][1]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if (wm * 2 + i >= m_blocks) break;             // wave-uniform
+            const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[i][1]);
+            acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][sb], 0, 0, 0);
+            acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][sb], 0, 0, 0);
+            acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][sb], 0, 0, 0);
+          }
+        }
+        if (ks == 0) { if (sb < 2) issue_pos(1 + sb); }    // pos 0 | 1 2 | 3 | 4 5(none)
+        else if (sb == 0) issue_pos(4);
+      }
+    }
+    dslot = dslot == WW_ND - 1 ? 0 : dslot + 1;
+    xslot ^= 1;
+  }
+
+  float* const slab = p.slab + (long long)blockIdx.x * WW_MROWS * p.Kcols;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (wm * 2 + i >= m_blocks) break;
+#pragma unroll
+    for (int sb = 0; sb < 3; ++sb) {
+      float* dst = slab + (long long)((wm * 2 + i) * 32 + 4 * half) * p.Kcols + g * (TZ_CW * 96) + wk * 96 + sb * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(long long)((r & 3) + 8 * (r >> 2)) * p.Kcols] = acc[i][sb][r];
+    }
+  }
+}
+
+// dw[m][c][k] = Σ_slabs slab[m][c·96 + k]: one thread per (m, c, k), four independent loads in flight
+__global__ __launch_bounds__(256) void tz_reduce_kernel(TzParams p) {
+  const int m = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int c = col / 96, k = col - c * 96;
+  if (c >= p.C || k >= p.K) return;
+  const float* q = p.slab + (long long)m * p.Kcols + col;
+  const long long st = (long long)WW_MROWS * p.Kcols;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int sl = 0;
+  for (; sl + 4 <= p.ksplit; sl += 4) {
+    s0 += q[(long long)sl * st]; s1 += q[(long long)(sl + 1) * st]; s2 += q[(long long)(sl + 2) * st]; s3 += q[(long long)(sl + 3) * st];
+  }
+  for (; sl < p.ksplit; ++sl) s0 += q[(long long)sl * st];
+  p.dw[((long long)m * p.C + c) * p.K + k] = (s0 + s1) + (s2 + s3);
+}
+
+static void tz_geometry(int B, int L, int M, int C, int K, int pad, TzParams* p) {
+  p->B = B; p->L = L; p->M = M; p->C = C; p->K = K;
+  p->P4 = ((pad + 3) & ~3) + 4;
+  p->off0 = p->P4 - pad;
+  p->n_groups = (C + TZ_CW - 1) / TZ_CW;
+  p->Kcols = p->n_groups * TZ_CW * 96;
+  p->tiles_per_seq = L / WW_TT;
+  p->n_tiles = B * p->tiles_per_seq;
+  const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
+  int ks = cus / p->n_groups;
+  if (ks > p->n_tiles) ks = p->n_tiles;
+  if (ks < 1) ks = 1;
+  p->ksplit = ks;
+}
+
+extern "C" int fst_dense_tap_wgrad_ok(int B, int L, int M, int C, int K, int pad_left) {
+  return B > 0 && L > 0 && L % WW_TT == 0 && M > 0 && M <= WW_MROWS && C > 0 && K > 4 && K <= 96 && pad_left >= 0 && pad_left < K;
+}
+
+extern "C" int64_t fst_dense_tap_wgrad_workspace_floats(int B, int L, int M, int C, int K) {
+  if (!fst_dense_tap_wgrad_ok(B, L, M, C, K, 0)) return -1;
+  TzParams p = {};
+  tz_geometry(B, L, M, C, K, 0, &p);
+  return (int64_t)p.ksplit * WW_MROWS * p.Kcols;
+}
+
+extern "C" int fst_dense_tap_wgrad(const float* dy, const float* x, float* dw, float* workspace, int64_t workspace_floats, int B, int L,
+                                   int M, int C, int K, int pad_left, int64_t numel_dy, int64_t numel_x, void* stream) {
+  FST_REQUIRE(dy && x && dw && workspace, "fst_dense_tap_wgrad: null operand");
+  FST_REQUIRE(fst_dense_tap_wgrad_ok(B, L, M, C, K, pad_left), "fst_dense_tap_wgrad: unsupported shape B=%d L=%d M=%d C=%d K=%d pad_left=%d "
+              "(needs L %% 32 == 0, M <= 256, 4 < K <= 96, 0 <= pad_left < K)", B, L, M, C, K, pad_left);
+  FST_REQUIRE((long long)B * M * L == (long long)numel_dy && (long long)B * C * L == (long long)numel_x,
+              "fst_dense_tap_wgrad: B*M*L / B*C*L do not match the element counts %lld / %lld", (long long)numel_dy, (long long)numel_x);
+  FST_REQUIRE(ww_al16(dy) && ww_al16(x) && ww_al16(workspace), "fst_dense_tap_wgrad: operands must be 16-byte aligned");
+  TzParams p = {};
+  tz_geometry(B, L, M, C, K, pad_left, &p);
+  FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * p.Kcols, "fst_dense_tap_wgrad: workspace of %lld floats is too small",
+              (long long)workspace_floats);
+  p.dy = dy; p.x = x; p.dw = dw; p.slab = workspace;
+  const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + 2 * TZ_CW * TZ_XRAW + TZ_COPIES;
+  if (int rc = fst_allow_full_lds((const void*)tz_wgrad_kernel, "fst_dense_tap_wgrad")) return rc;
+  hipLaunchKernelGGL(tz_wgrad_kernel, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tz_reduce_kernel, dim3((unsigned)((p.C * 96 + 255) / 256), (unsigned)M), dim3(256), 0, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}

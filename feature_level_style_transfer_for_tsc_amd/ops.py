@@ -330,6 +330,17 @@ class ConvSpec:
         self._plans: Dict[Tuple[str, int], Plan] = {}
         self.mb = 1 if self.row_live is not None and ntaps > 2 else pick_mb(M)
 
+    def dense_tap_wgrad_ok(self, B: int, L: int, x0: Tensor, dy: Tensor) -> bool:
+        """Whether ``dense_tap_wgrad`` serves this conv's weight gradient: a DENSE gradient (quirk Q1 layers, or no tap mask) over 5..96
+        taps at dilation 1, no side input, at most 256 output rows, L % 32 == 0, split-bf16 mode, contiguous 16-byte aligned operands."""
+        if self.C1 or MATH != "bf16x3" or not (self.dense_dw or self.row_live is None) or self.dil != 1:
+            return False
+        if os.environ.get("FST_DENSE_TAP_WGRAD", "1") == "0" or not (x0.is_contiguous() and dy.is_contiguous()):
+            return False
+        if x0.data_ptr() % 16 or dy.data_ptr() % 16 or dy.size(1) != self.M or x0.size(1) != self.C0:
+            return False
+        return bool(_lib.load().fst_dense_tap_wgrad_ok(B, L, self.M, self.C0, self.ntaps, self.pad_left))
+
     def tap_wgrad_ok(self, B: int, L: int, x0: Tensor, dy: Tensor) -> bool:
         """Whether ``tap_wgrad`` (csrc/wn_wgrad.hip) serves this conv's DENSE weight gradient: no side input, every tap wanted (a dense
         plan, or no tap mask at all), at most four taps, split-bf16 mode, contiguous operands — and slack around x when a tap is shifted
@@ -528,6 +539,11 @@ class ConvSpec:
         ``out0`` / ``out1``: contiguous [M, C0, ntaps] / [M, C1, 1] tensors (segments of a flat gradient, zero-filled when
         the plan does not write every element) that receive the gradients in place."""
         B, L = x0.size(0), x0.size(2)
+        if x1 is None and dy2 is None and msplit is None and not x0_mul_off and self.dense_tap_wgrad_ok(B, L, x0, dy):
+            # the dense gradient of an omni-scale layer (Q1): every tap from eight pre-shifted copies of one staged window per channel
+            dw0 = out0 if out0 is not None else torch.empty(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
+            dense_tap_wgrad(dy, x0, dw0, self.M, self.C0, self.ntaps, self.pad_left)
+            return dw0, None
         if x1 is None and dy2 is None and msplit is None and not x0_mul_off and self.tap_wgrad_ok(B, L, x0, dy):
             # dense gradient of a conv with a few taps: the time-as-k kernel (each tap a k-row segment with its own shift)
             dw0 = out0 if out0 is not None else torch.empty(self.M, self.C0, self.ntaps, device=x0.device, dtype=torch.float32)
@@ -873,6 +889,25 @@ def wn_wgrad_rs(d_a, d_out, ts, dw_rs: Tensor, last: bool, n: int) -> None:
                               int(last), B, L, n, numel, stream_ptr()), "fst_wn_wgrad_rs")
     if t0 is not None:
         KERNEL_TIMER.end("wn_wgrad_kernel<2, 2> bf3", t0, 2.0 * ns * B * L * M * n, 4.0 * ns * B * L * (M + 2 * n))
+
+
+def dense_tap_wgrad(dy: Tensor, x: Tensor, dw: Tensor, M: int, C: int, K: int, pad_left: int) -> None:
+    """dw [M, C, K] = Σ_{b,t} dy[b, m, t]·x[b, c, t + k − pad_left] for every tap k < K <= 96 — written in place (fst_dense_tap_wgrad)."""
+    lib = _lib.load()
+    B, _, L = dy.shape
+    if tuple(dy.shape) != (B, M, L) or tuple(x.shape) != (B, C, L) or not (dy.is_contiguous() and x.is_contiguous()):
+        raise ValueError(f"dense_tap_wgrad: dy {tuple(dy.shape)} / x {tuple(x.shape)} must be contiguous [B, {M}, L] / [B, {C}, L]")
+    if tuple(dw.shape) != (M, C, K) or not dw.is_contiguous() or dw.dtype != torch.float32:
+        raise ValueError(f"dense_tap_wgrad: gradient target of shape {tuple(dw.shape)}, expected contiguous {(M, C, K)}")
+    ws_n = lib.fst_dense_tap_wgrad_workspace_floats(B, L, M, C, K)
+    if ws_n <= 0:
+        raise ValueError(f"dense_tap_wgrad: unsupported shape B={B} L={L} M={M} C={C} K={K}")
+    ws = torch.empty(ws_n, device=dy.device, dtype=torch.float32)
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_dense_tap_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(ws), ws_n, B, L, M, C, K, pad_left, dy.numel(), x.numel(), stream_ptr()),
+          "fst_dense_tap_wgrad")
+    if t0 is not None:
+        KERNEL_TIMER.end(f"tz_wgrad_kernel M={M} C={C} bf3", t0, 2.0 * B * L * M * C * K, 4.0 * B * L * (M + C))
 
 
 def tap_wgrad(dy: Tensor, x: Tensor, dw: Tensor, M: int, C: int, ntaps: int, dil: int, pad_left: int) -> None:

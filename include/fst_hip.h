@@ -301,6 +301,16 @@ int fst_tap_wgrad(const float* dy, const float* x, float* dw /* [M][C][ntaps], w
                   int B, int L, int M, int C, int ntaps, int dil, int pad_left, int x_slack, int64_t numel_dy, int64_t numel_x,
                   void* stream);
 
+/* The DENSE weight gradient of an omni-scale layer (every tap k < K <= 96 of every row, dilation 1; quirk Q1: the reference convolves the
+ * dense Kmax kernel, /root/reference/OS_CNN/OS_CNN.py:67-71, and GradNorm's norms, train_and_test.py:685-690, run over the dense gradient):
+ *   dw[m][c][k] = Σ_{b,t} dy[b][m][t]·x[b][c][t + k − pad_left]          (M <= 256, L % 32 == 0)
+ * time as the MFMA reduction index; the K k-rows of a channel are read from eight pre-shifted bf16 copies of ONE staged window of the
+ * channel (csrc/wn_wgrad.hip).  Partial slabs in `workspace` (fst_dense_tap_wgrad_workspace_floats), added in a fixed order: no atomics. */
+int fst_dense_tap_wgrad_ok(int B, int L, int M, int C, int K, int pad_left);
+int64_t fst_dense_tap_wgrad_workspace_floats(int B, int L, int M, int C, int K);
+int fst_dense_tap_wgrad(const float* dy, const float* x, float* dw /* [M][C][K], written */, float* workspace, int64_t workspace_floats,
+                        int B, int L, int M, int C, int K, int pad_left, int64_t numel_dy, int64_t numel_x, void* stream);
+
 /* NoiseTransfer (/root/reference/widgets.py:150-167): new_t = avg_t + r_t·mean_b(z_t), new_s likewise, dist = new_t − new_s,
  * learned = selu(W·dist + bias) (unbatched 1x1 conv over the [C, L] map), out[b] = learned + z_s[b].
  *   fst_batch_sum            part[z][s][i] = Σ_{b in slice s} x_z[b][i] (z < 2 tensors, x1 may be NULL; S contiguous slices of the

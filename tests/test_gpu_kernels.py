@@ -691,3 +691,20 @@ def test_few_tap_dense_weight_gradient_vs_fp64(M, C, ntaps, dil, pad, Bq, L, mon
     assert torch.equal(dw, again)
     if any((k * dil - pad) % 4 for k in range(ntaps)):
         assert not spec.tap_wgrad_ok(Bq, L, x.clone(), dy)                      # no slack: the generic kernel serves it
+
+
+@pytest.mark.parametrize("M,C,K,pad,Bq,L", [(225, 25, 89, 44, 256, 512), (25, 1, 89, 44, 256, 512), (225, 25, 89, 44, 2, 64), (33, 3, 37, 18, 3, 96),
+                                            (7, 2, 5, 2, 1, 32), (256, 5, 96, 47, 2, 64), (40, 4, 8, 3, 2, 128)])
+def test_dense_many_tap_weight_gradient_vs_fp64(M, C, K, pad, Bq, L):
+    """fst_dense_tap_wgrad (the dense Q1 gradient of an omni-scale layer: every tap from eight pre-shifted copies of one staged window
+    per channel) against an fp64 einsum — through ConvSpec.grad_w, which routes dense plans there; bit-identical twice."""
+    g = torch.Generator(device=DEV).manual_seed(M + C + K + L)
+    x, dy = torch.randn(Bq, C, L, generator=g, device=DEV), torch.randn(Bq, M, L, generator=g, device=DEV)
+    spec = ops.ConvSpec(M, C, K, 1, pad)
+    assert spec.dense_tap_wgrad_ok(Bq, L, x, dy)
+    dw, _ = spec.grad_w(x, None, dy)
+    xp = F.pad(x.double(), (pad, K - 1 - pad))
+    want = torch.stack([torch.einsum("bmt,bct->mc", dy.double(), xp[:, :, k: k + L]) for k in range(K)], dim=2)
+    assert_close(dw, want, 1e-4, "dense many-tap dW")
+    again, _ = spec.grad_w(x, None, dy)
+    assert torch.equal(dw, again)
