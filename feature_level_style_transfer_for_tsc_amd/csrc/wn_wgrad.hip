@@ -800,11 +800,11 @@ extern "C" int fst_tap_wgrad(const float* dy, const float* x, float* dw, float* 
 // by 0..7 samples.  The B fragment of k-row "shift s" at samples t.. t+7 is then the 16-byte aligned unit ⌊o/8⌋ of copy o mod 8
 // (o = s + t − window start): one ds_read_b128 per part, no per-shift staging — the item-table kernel stages every (tap, channel)
 // row on its own and reaches 0.23 of the matrix peak on the 225 × 25 × 89 layer.
-// A workgroup = all M rows × TZ_CW channels × 3 blocks of 32 shifts; waves 4 (row pairs) × 2 (channels), 2 × 3 tiles each.
-#define TZ_CW 2
+// A workgroup = all M rows × CW channels × 3 blocks of 32 shifts; its 8 waves = MP row pairs × CW = 8/MP channels, 2 × 3 tiles of
+// 32 × 32 each: MP = 4 (up to 256 rows, 2 channels), 2 (up to 128 rows, 4 channels) or 1 (up to 64 rows, 8 channels) — few-row layers
+// (the first omni-scale layer: 25 rows) put their waves on channels instead of on row blocks that do not exist.
 #define TZ_CPB 288                                         // bytes per shifted copy: 16 units of 16 B + 32 (16-lane groups then hit all banks)
 #define TZ_XRAW 1024                                       // bytes per staged raw window (40 of 64 pieces used)
-#define TZ_COPIES (TZ_CW * 2 * 8 * TZ_CPB)
 
 struct TzParams {
   const float* dy;      // [B][M][L]
@@ -828,11 +828,13 @@ __device__ __forceinline__ void tz_wait_at_most() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int MP>
 __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
+  constexpr int TZ_CW = 8 / MP;
   extern __shared__ __attribute__((aligned(16))) char tz_lds[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave_s >> 1, wk = wave_s & 1;
+  const int wm = wave_s / TZ_CW, wk = wave_s % TZ_CW;       // row pair, channel of the group
   const int g = blockIdx.y, L = p.L;
   constexpr int dslot_bytes = WW_MROWS * 128;
   char* const xraw = tz_lds + WW_ND * dslot_bytes;          // [2 slots][TZ_CW][TZ_XRAW]
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
     dsrc[k].p = r < p.M ? p.dy + ((long long)r * L + 4 * q) : nullptr;
     dsrc[k].bs = 0; dsrc[k].t = 4 * q;
   }
-  // ---- the window of channel 2g + wave (waves 0, 1): piece `lane` (< 40) of the 160 samples from t0 − P4
+  // ---- the window of channel CW·g + wave (waves < CW): piece `lane` (< 40) of the 160 samples from t0 − P4
   const int my_ch = TZ_CW * g + wave_s;
   const float* const xrow = (wave_s < TZ_CW && my_ch < p.C && lane < 40) ? p.x + ((long long)my_ch * L + 4 * lane) : nullptr;
   const long long dy_bs = (long long)p.M * L, x_bs = (long long)p.C * L;
@@ -950,12 +952,17 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
         da[i][0] = dw + ww_lds_off(r, 2 * u); da[i][1] = dw + ww_lds_off(r, 2 * u + 1);
         if (r < dy_rows) { d[i][0] = ww_lds_read16(da[i][0]); d[i][1] = ww_lds_read16(da[i][1]); }
       }
-      float xv[8];
-      const int xc = tid >> 7, xr = (tid >> 4) & 7, xq = tid & 15;
-      if (tid < 128 * TZ_CW) {
-        const char* src = xraw + (xslot * TZ_CW + xc) * TZ_XRAW + (8 * xq + xr) * 4;
+      constexpr int XU = (128 * TZ_CW + 511) / 512;         // copy units per thread (unit id = tid + 512·j)
+      float xv[XU][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xv[j] = tz_lds_read4(src + 4 * j);
+      for (int j = 0; j < XU; ++j) {
+        const int id = tid + 512 * j;
+        if (id < 128 * TZ_CW) {
+          const int xc = id >> 7, xr = (id >> 4) & 7, xq = id & 15;
+          const char* src = xraw + (xslot * TZ_CW + xc) * TZ_XRAW + (8 * xq + xr) * 4;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[j][e] = tz_lds_read4(src + 4 * e);
+        }
       }
       ww_lds_wait();
 #pragma unroll
@@ -967,14 +974,19 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
           ww_lds_write16(da[i][0], h4); ww_lds_write16(da[i][1], l4);
         }
       }
-      if (tid < 128 * TZ_CW) {
-        ww_u32x4 h4, l4;
-        unsigned hh, ll;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ww_split_pair(xv[2 * j], xv[2 * j + 1], hh, ll); h4[j] = hh; l4[j] = ll; }
-        char* dst = copies + xc * (8 * TZ_CPB) + xr * TZ_CPB + (xq << 4);
-        ww_lds_write16(dst, h4);
-        ww_lds_write16(dst + TZ_CW * 8 * TZ_CPB, l4);
+      for (int j = 0; j < XU; ++j) {
+        const int id = tid + 512 * j;
+        if (id < 128 * TZ_CW) {
+          const int xc = id >> 7, xr = (id >> 4) & 7, xq = id & 15;
+          ww_u32x4 h4, l4;
+          unsigned hh, ll;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ww_split_pair(xv[j][2 * e], xv[j][2 * e + 1], hh, ll); h4[e] = hh; l4[e] = ll; }
+          char* dst = copies + xc * (8 * TZ_CPB) + xr * TZ_CPB + (xq << 4);
+          ww_lds_write16(dst, h4);
+          ww_lds_write16(dst + TZ_CW * 8 * TZ_CPB, l4);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -1049,7 +1061,8 @@ __global__ __launch_bounds__(256) void tz_reduce_kernel(TzParams p) {
   p.dw[((long long)m * p.C + c) * p.K + k] = (s0 + s1) + (s2 + s3);
 }
 
-static void tz_geometry(int B, int L, int M, int C, int K, int pad, TzParams* p) {
+static int tz_geometry(int B, int L, int M, int C, int K, int pad, TzParams* p) {
+  const int MP = M <= 64 ? 1 : (M <= 128 ? 2 : 4), TZ_CW = 8 / MP;
   p->B = B; p->L = L; p->M = M; p->C = C; p->K = K;
   p->P4 = ((pad + 3) & ~3) + 4;
   p->off0 = p->P4 - pad;
@@ -1062,6 +1075,7 @@ static void tz_geometry(int B, int L, int M, int C, int K, int pad, TzParams* p)
   if (ks > p->n_tiles) ks = p->n_tiles;
   if (ks < 1) ks = 1;
   p->ksplit = ks;
+  return MP;
 }
 
 extern "C" int fst_dense_tap_wgrad_ok(int B, int L, int M, int C, int K, int pad_left) {
@@ -1071,7 +1085,7 @@ extern "C" int fst_dense_tap_wgrad_ok(int B, int L, int M, int C, int K, int pad
 extern "C" int64_t fst_dense_tap_wgrad_workspace_floats(int B, int L, int M, int C, int K) {
   if (!fst_dense_tap_wgrad_ok(B, L, M, C, K, 0)) return -1;
   TzParams p = {};
-  tz_geometry(B, L, M, C, K, 0, &p);
+  (void)tz_geometry(B, L, M, C, K, 0, &p);
   return (int64_t)p.ksplit * WW_MROWS * p.Kcols;
 }
 
@@ -1084,13 +1098,15 @@ extern "C" int fst_dense_tap_wgrad(const float* dy, const float* x, float* dw, f
               "fst_dense_tap_wgrad: B*M*L / B*C*L do not match the element counts %lld / %lld", (long long)numel_dy, (long long)numel_x);
   FST_REQUIRE(ww_al16(dy) && ww_al16(x) && ww_al16(workspace), "fst_dense_tap_wgrad: operands must be 16-byte aligned");
   TzParams p = {};
-  tz_geometry(B, L, M, C, K, pad_left, &p);
+  const int MP = tz_geometry(B, L, M, C, K, pad_left, &p);
   FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * p.Kcols, "fst_dense_tap_wgrad: workspace of %lld floats is too small",
               (long long)workspace_floats);
   p.dy = dy; p.x = x; p.dw = dw; p.slab = workspace;
-  const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + 2 * TZ_CW * TZ_XRAW + TZ_COPIES;
-  if (int rc = fst_allow_full_lds((const void*)tz_wgrad_kernel, "fst_dense_tap_wgrad")) return rc;
-  hipLaunchKernelGGL(tz_wgrad_kernel, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
+  const int cw = 8 / MP;
+  const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + 2 * cw * TZ_XRAW + (size_t)cw * 2 * 8 * TZ_CPB;
+  void (*fn)(TzParams) = MP == 1 ? tz_wgrad_kernel<1> : (MP == 2 ? tz_wgrad_kernel<2> : tz_wgrad_kernel<4>);
+  if (int rc = fst_allow_full_lds((const void*)fn, "fst_dense_tap_wgrad")) return rc;
+  hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   hipLaunchKernelGGL(tz_reduce_kernel, dim3((unsigned)((p.C * 96 + 255) / 256), (unsigned)M), dim3(256), 0, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();

@@ -323,6 +323,9 @@ class ConvSpec:
         self.M, self.C0, self.ntaps, self.dil, self.pad_left, self.C1 = M, C0, ntaps, dil, pad_left, C1
         self.row_live = list(row_live) if row_live is not None else None
         self.dense_dw = dense_dw
+        # a layer whose masked-tap gradients nobody reads (the classifier) still takes the dense many-tap kernel where that serves its
+        # shape — it is faster than the live-tap item-table plan, and the masked taps then hold the reference's dense values, not zeros
+        self.dense_if_fast = False
         if C1:
             if pad_left % dil or not (0 <= pad_left // dil < ntaps):
                 raise ValueError("the 1x1 side input needs a tap with zero offset")
@@ -333,7 +336,7 @@ class ConvSpec:
     def dense_tap_wgrad_ok(self, B: int, L: int, x0: Tensor, dy: Tensor) -> bool:
         """Whether ``dense_tap_wgrad`` serves this conv's weight gradient: a DENSE gradient (quirk Q1 layers, or no tap mask) over 5..96
         taps at dilation 1, no side input, at most 256 output rows, L % 32 == 0, split-bf16 mode, contiguous 16-byte aligned operands."""
-        if self.C1 or MATH != "bf16x3" or not (self.dense_dw or self.row_live is None) or self.dil != 1:
+        if self.C1 or MATH != "bf16x3" or not (self.dense_dw or self.row_live is None or self.dense_if_fast) or self.dil != 1:
             return False
         if os.environ.get("FST_DENSE_TAP_WGRAD", "1") == "0" or not (x0.is_contiguous() and dy.is_contiguous()):
             return False

@@ -140,9 +140,12 @@ class OS_CNN(nn.Module):
         super().__init__()
         self.few_shot = few_shot
         self.layer_parameter_list = layer_parameter_list
-        # weight gradients on live taps only: nothing reads the classifier's masked-tap gradients (GradNorm
-        # differentiates the feature extractor's OS_block), and masked weights are re-zeroed every forward
+        # nothing reads the classifier's masked-tap gradients (GradNorm differentiates the feature extractor's OS_block) and masked
+        # weights are re-zeroed every forward: a masked tap's gradient is either not computed (0: the live-tap plans) or the reference's
+        # dense value (where the dense many-tap kernel serves the layer: it is the faster of the two)
         self.layer_list = [build_layer_with_layer_parameter(lp, dense_weight_grad=False) for lp in layer_parameter_list]
+        for layer in self.layer_list:
+            layer.spec.dense_if_fast = True
         self.net = nn.Sequential(*self.layer_list)
         self.averagepool = nn.AdaptiveAvgPool1d(1)
         width = out_channels(layer_parameter_list[-1])
