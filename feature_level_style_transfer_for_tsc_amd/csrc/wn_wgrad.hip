@@ -801,8 +801,9 @@ extern "C" int fst_tap_wgrad(const float* dy, const float* x, float* dw, float* 
 // (o = s + t − window start): one ds_read_b128 per part, no per-shift staging — the item-table kernel stages every (tap, channel)
 // row on its own and reaches 0.23 of the matrix peak on the 225 × 25 × 89 layer.
 // A workgroup = all M rows × CW channels × 3 blocks of 32 shifts; its 8 waves = MP row pairs × CW = 8/MP channels, 2 × 3 tiles of
-// 32 × 32 each: MP = 4 (up to 256 rows, 2 channels), 2 (up to 128 rows, 4 channels) or 1 (up to 64 rows, 8 channels) — few-row layers
-// (the first omni-scale layer: 25 rows) put their waves on channels instead of on row blocks that do not exist.
+// 32 × 32 each: MP = 2 (128 rows, 4 channels) or 1 (up to 64 rows, 8 channels) — few-row layers (the first omni-scale layer: 25 rows)
+// put their waves on channels instead of on row blocks that do not exist; more than 128 rows are two row halves (blockIdx.z), each
+// streaming only its own dy rows: dy is then staged by ⌈C/4⌉ channel groups instead of ⌈C/2⌉ (225 × 25 × 89: 551 → … µs).
 #define TZ_CPB 288                                         // bytes per shifted copy: 16 units of 16 B + 32 (16-lane groups then hit all banks)
 #define TZ_XRAW 1024                                       // bytes per staged raw window (40 of 64 pieces used)
 
@@ -814,6 +815,7 @@ struct TzParams {
   int B, L, M, C, K, P4;        // P4: the window of stage t0 starts at sample t0 − P4 (pad rounded up to 4, plus 4)
   int off0;                     // P4 − pad: window offset of (shift 0, sample t0)
   int n_groups, ksplit, tiles_per_seq, n_tiles, Kcols;
+  int m_halves;                 // 1, or 2: workgroup z takes the rows [128·z, min(M, 128·z + 128))
 };
 
 __device__ __forceinline__ float tz_lds_read4(const char* p) {
@@ -841,15 +843,17 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
   char* const copies = xraw + 2 * TZ_CW * TZ_XRAW;          // [hi | lo][TZ_CW][8 copies][TZ_CPB]
   const char* const zero16 = reinterpret_cast<const char*>(ww_zero16);
 
-  // ---- dy rows: ⌈M/8⌉ LDS-DMA instructions per stage (8 rows each), instruction i = wave + 8k
-  const int nd = (p.M + 7) >> 3;
+  // ---- dy rows of this row half: ⌈M_here/8⌉ LDS-DMA instructions per stage (8 rows each), instruction i = wave + 8k
+  const int m_base = blockIdx.z * 128;
+  const int M_here = p.m_halves > 1 ? min(128, p.M - m_base) : p.M;
+  const int nd = (M_here + 7) >> 3;
   const int my_nd = nd > wave_s ? (nd - wave_s + 7) >> 3 : 0;
   WwSrc dsrc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = wave_s + 8 * k;
     const int r = ww_dma_row(i, lane), q = (lane ^ r) & 7;
-    dsrc[k].p = r < p.M ? p.dy + ((long long)r * L + 4 * q) : nullptr;
+    dsrc[k].p = r < M_here ? p.dy + ((long long)(m_base + r) * L + 4 * q) : nullptr;
     dsrc[k].bs = 0; dsrc[k].t = 4 * q;
   }
   // ---- the window of channel CW·g + wave (waves < CW): piece `lane` (< 40) of the 160 samples from t0 − P4
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
 
   const int tile_begin = (int)(((long long)blockIdx.x * p.n_tiles) / p.ksplit);
   const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.n_tiles) / p.ksplit);
-  const int m_blocks = (p.M + 31) >> 5;
+  const int m_blocks = (M_here + 31) >> 5;
   const int k_blocks = (p.K + 31) >> 5;                    // live 32-shift blocks (<= 3)
   const bool ch_live = TZ_CW * g + wk < p.C;
 
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
     if (wm * 2 + i >= m_blocks) break;
 #pragma unroll
     for (int sb = 0; sb < 3; ++sb) {
-      float* dst = slab + (long long)((wm * 2 + i) * 32 + 4 * half) * p.Kcols + g * (TZ_CW * 96) + wk * 96 + sb * 32 + l31;
+      float* dst = slab + (long long)(m_base + (wm * 2 + i) * 32 + 4 * half) * p.Kcols + g * (TZ_CW * 96) + wk * 96 + sb * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[(long long)((r & 3) + 8 * (r >> 2)) * p.Kcols] = acc[i][sb][r];
     }
@@ -1062,7 +1066,8 @@ __global__ __launch_bounds__(256) void tz_reduce_kernel(TzParams p) {
 }
 
 static int tz_geometry(int B, int L, int M, int C, int K, int pad, TzParams* p) {
-  const int MP = M <= 64 ? 1 : (M <= 128 ? 2 : 4), TZ_CW = 8 / MP;
+  const int MP = M <= 64 ? 1 : 2, TZ_CW = 8 / MP;
+  p->m_halves = M > 128 ? 2 : 1;
   p->B = B; p->L = L; p->M = M; p->C = C; p->K = K;
   p->P4 = ((pad + 3) & ~3) + 4;
   p->off0 = p->P4 - pad;
@@ -1071,7 +1076,7 @@ static int tz_geometry(int B, int L, int M, int C, int K, int pad, TzParams* p) 
   p->tiles_per_seq = L / WW_TT;
   p->n_tiles = B * p->tiles_per_seq;
   const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
-  int ks = cus / p->n_groups;
+  int ks = cus / (p->n_groups * p->m_halves);
   if (ks > p->n_tiles) ks = p->n_tiles;
   if (ks < 1) ks = 1;
   p->ksplit = ks;
@@ -1104,9 +1109,9 @@ extern "C" int fst_dense_tap_wgrad(const float* dy, const float* x, float* dw, f
   p.dy = dy; p.x = x; p.dw = dw; p.slab = workspace;
   const int cw = 8 / MP;
   const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + 2 * cw * TZ_XRAW + (size_t)cw * 2 * 8 * TZ_CPB;
-  void (*fn)(TzParams) = MP == 1 ? tz_wgrad_kernel<1> : (MP == 2 ? tz_wgrad_kernel<2> : tz_wgrad_kernel<4>);
+  void (*fn)(TzParams) = MP == 1 ? tz_wgrad_kernel<1> : tz_wgrad_kernel<2>;
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_dense_tap_wgrad")) return rc;
-  hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups), dim3(512), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups, (unsigned)p.m_halves), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   hipLaunchKernelGGL(tz_reduce_kernel, dim3((unsigned)((p.C * 96 + 255) / 256), (unsigned)M), dim3(256), 0, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
