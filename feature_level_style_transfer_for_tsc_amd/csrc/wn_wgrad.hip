@@ -816,6 +816,7 @@ struct TzParams {
   int off0;                     // P4 − pad: window offset of (shift 0, sample t0)
   int n_groups, ksplit, tiles_per_seq, n_tiles, Kcols;
   int m_halves;                 // 1, or 2: workgroup z takes the rows [128·z, min(M, 128·z + 128))
+  int exp;                      // diagnostics (FST_TZ_EXP, timing only, wrong results): 1 no MFMAs, 2 no split pass, 4 no LDS-DMA
 };
 
 __device__ __forceinline__ float tz_lds_read4(const char* p) {
@@ -867,13 +868,13 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
     t0 = (tile - b * p.tiles_per_seq) * WW_TT;
   };
   auto issue_dy1 = [&](int k, int b, int t0, int slot) {
-    if (k >= my_nd) return;                                // wave-uniform
+    if (k >= my_nd || (p.exp & 4)) return;                 // wave-uniform
     const bool ok = dsrc[k].p != nullptr;
     const char* src = ok ? reinterpret_cast<const char*>(dsrc[k].p + (b * dy_bs + t0)) : zero16;
     ww_dma16(src, tz_lds + slot * dslot_bytes + (wave_s + 8 * k) * 1024);
   };
   auto issue_x1 = [&](int b, int t0, int slot) {
-    if (wave_s >= TZ_CW) return;                           // wave-uniform
+    if (wave_s >= TZ_CW || (p.exp & 4)) return;            // wave-uniform
     const int t = t0 - p.P4 + 4 * lane;                    // (multiples of 4: a piece is inside the sequence or outside it)
     const bool ok = xrow != nullptr && t >= 0 && t < L;
     const char* src = ok ? reinterpret_cast<const char*>(xrow + (b * x_bs + t0 - p.P4)) : zero16;
@@ -944,7 +945,7 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
     };
     // ---- split pass.  dy: in place (thread t: units t and t + 512 = rows t>>2 and 128 + (t>>2), unit t&3).  x: thread t < 256 builds
     // unit q = t & 15 of copy r = (t >> 4) & 7 of channel t >> 7: window samples 8q + r .. 8q + r + 7
-    {
+    if (!(p.exp & 2)) {
       char* const dw = tz_lds + dslot * dslot_bytes;
       const int u = tid & 3, r0 = tid >> 2;
       ww_f32x4 d[2][2];
@@ -1016,7 +1017,7 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
       issue_pos(3 * ks);
 #pragma unroll
       for (int sb = 0; sb < 3; ++sb) {
-        if (sb < k_blocks && ch_live) {                    // wave-uniform
+        if (sb < k_blocks && ch_live && !(p.exp & 1)) {    // wave-uniform
           const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[sb][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[sb][1]);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
@@ -1107,6 +1108,8 @@ extern "C" int fst_dense_tap_wgrad(const float* dy, const float* x, float* dw, f
   FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * p.Kcols, "fst_dense_tap_wgrad: workspace of %lld floats is too small",
               (long long)workspace_floats);
   p.dy = dy; p.x = x; p.dw = dw; p.slab = workspace;
+  static const int exp_env = getenv("FST_TZ_EXP") ? atoi(getenv("FST_TZ_EXP")) : 0;
+  p.exp = exp_env;
   const int cw = 8 / MP;
   const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + 2 * cw * TZ_XRAW + (size_t)cw * 2 * 8 * TZ_CPB;
   void (*fn)(TzParams) = MP == 1 ? tz_wgrad_kernel<1> : tz_wgrad_kernel<2>;
