@@ -996,39 +996,46 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    // ---- multiply
+    // ---- multiply.  The fragment reads of the second k-step are issued BEFORE the MFMAs of the first (two register sets): behind one
+    // another, reads (10 × 1 KiB per wave and k-step: 0.5 µs of LDS time per stage and CU) and MFMAs (0.96 µs) added up
     const char* const dsl = tz_lds + dslot * dslot_bytes;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      ww_f32x4 araw[2][2], braw[3][2];
+    ww_f32x4 araw[2][2][2], braw[2][3][2];
+    auto read_frags = [&](int ks) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const char* ap = dsl + a_off + ((i * 32) << 7);
-        araw[i][0] = ww_lds_read16(ap + pc[ks][0]);
-        araw[i][1] = ww_lds_read16(ap + pc[ks][1]);
+        araw[ks][i][0] = ww_lds_read16(ap + pc[ks][0]);
+        araw[ks][i][1] = ww_lds_read16(ap + pc[ks][1]);
       }
 #pragma unroll
       for (int sb = 0; sb < 3; ++sb) {
         const char* bp = copies + b_off + ((2 * ks + 4 * sb) << 4);
-        braw[sb][0] = ww_lds_read16(bp);
-        braw[sb][1] = ww_lds_read16(bp + TZ_CW * 8 * TZ_CPB);
+        braw[ks][sb][0] = ww_lds_read16(bp);
+        braw[ks][sb][1] = ww_lds_read16(bp + TZ_CW * 8 * TZ_CPB);
       }
-      ww_lds_wait();
+    };
+    read_frags(0);
+    ww_lds_wait();
+    read_frags(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 1) ww_lds_wait();
       issue_pos(3 * ks);
 #pragma unroll
       for (int sb = 0; sb < 3; ++sb) {
         if (sb < k_blocks && ch_live && !(p.exp & 1)) {    // wave-uniform
-          const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[sb][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[sb][1]);
+          const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[ks][sb][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[ks][sb][1]);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             if (wm * 2 + i >= m_blocks) break;             // wave-uniform
-            const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[i][1]);
+            const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[ks][i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[ks][i][1]);
             acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][sb], 0, 0, 0);
             acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][sb], 0, 0, 0);
             acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][sb], 0, 0, 0);
           }
         }
-        if (ks == 0) { if (sb < 2) issue_pos(1 + sb); }    // pos 0 | 1 2 | 3 | 4 5(none)
+        if (ks == 0) { if (sb < 2) issue_pos(1 + sb); }    // pos 0 | 1 2 | 3 | 4
         else if (sb == 0) issue_pos(4);
       }
     }
