@@ -800,14 +800,10 @@ extern "C" int fst_tap_wgrad(const float* dy, const float* x, float* dw, float* 
 // by 0..7 samples.  The B fragment of k-row "shift s" at samples t.. t+7 is then the 16-byte aligned unit ⌊o/8⌋ of copy o mod 8
 // (o = s + t − window start): one ds_read_b128 per part, no per-shift staging — the item-table kernel stages every (tap, channel)
 // row on its own and reaches 0.23 of the matrix peak on the 225 × 25 × 89 layer.
-// Two shapes of workgroup, both with 2 × 3 tiles of 32 × 32 per wave (96 accumulator registers):
-//   many rows (M > 64):  4 waves = 2 row pairs × 2 channels on a HALF of 128 rows (blockIdx.z = ⌈M/128⌉ halves), 61 KB of LDS — TWO
-//                        workgroups per CU, which run out of step: one's split pass and barriers sit beside the other's MFMAs
-//                        (an 8-wave workgroup alone on its CU went through those phases one after the other: 647 µs → … on
-//                        225 × 25 × 89 at B=256, L=512; `FST_TZ_EXP` cost removal: MFMAs 268 µs, split pass 194, LDS-DMA 106, the
-//                        rest — barriers, fragment reads, slab stores, reduce — 232, all of it additive);
-//   few rows (M <= 64):  8 waves = 1 row pair × 8 channels (the first omni-scale layer has 25 rows: its waves go on channels, not
-//                        on row blocks that do not exist).
+// A workgroup = all M rows × CW channels × 3 blocks of 32 shifts; its 8 waves = MP row pairs × CW = 8/MP channels, 2 × 3 tiles of
+// 32 × 32 each: MP = 2 (128 rows, 4 channels) or 1 (up to 64 rows, 8 channels) — few-row layers (the first omni-scale layer: 25 rows)
+// put their waves on channels instead of on row blocks that do not exist; more than 128 rows are two row halves (blockIdx.z), each
+// streaming only its own dy rows: dy is then staged by ⌈C/4⌉ channel groups instead of ⌈C/2⌉ (225 × 25 × 89: 551 → … µs).
 #define TZ_CPB 288                                         // bytes per shifted copy: 16 units of 16 B + 32 (16-lane groups then hit all banks)
 #define TZ_XRAW 1024                                       // bytes per staged raw window (40 of 64 pieces used)
 
@@ -819,7 +815,7 @@ struct TzParams {
   int B, L, M, C, K, P4;        // P4: the window of stage t0 starts at sample t0 − P4 (pad rounded up to 4, plus 4)
   int off0;                     // P4 − pad: window offset of (shift 0, sample t0)
   int n_groups, ksplit, tiles_per_seq, n_tiles, Kcols;
-  int m_halves;                 // workgroup z takes the rows [DYR·z, min(M, DYR·z + DYR)), DYR = 128 (64 in the few-row form: one half)
+  int m_halves;                 // 1, or 2: workgroup z takes the rows [128·z, min(M, 128·z + 128))
   int exp;                      // diagnostics (FST_TZ_EXP, timing only, wrong results): 1 no MFMAs, 2 no split pass, 4 no LDS-DMA
 };
 
@@ -835,30 +831,28 @@ __device__ __forceinline__ void tz_wait_at_most() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// NW waves = MP row pairs × CW channels; DYR = dy rows staged per stage (64·MP)
-template <int NW, int MP>
-__global__ __launch_bounds__(64 * NW, 2) void tz_wgrad_kernel(TzParams p) {
-  constexpr int TZ_CW = NW / MP, DYR = 64 * MP, NT = 64 * NW;
+template <int MP>
+__global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
+  constexpr int TZ_CW = 8 / MP;
   extern __shared__ __attribute__((aligned(16))) char tz_lds[];
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave_s / TZ_CW, wk = wave_s % TZ_CW;       // row pair, channel of the group
   const int g = blockIdx.y, L = p.L;
-  constexpr int dslot_bytes = DYR * 128;
+  constexpr int dslot_bytes = WW_MROWS * 128;
   char* const xraw = tz_lds + WW_ND * dslot_bytes;          // [2 slots][TZ_CW][TZ_XRAW]
   char* const copies = xraw + 2 * TZ_CW * TZ_XRAW;          // [hi | lo][TZ_CW][8 copies][TZ_CPB]
   const char* const zero16 = reinterpret_cast<const char*>(ww_zero16);
 
-  // ---- dy rows of this row half: ⌈M_here/8⌉ LDS-DMA instructions per stage (8 rows each), instruction i = wave + NW·k
-  const int m_base = blockIdx.z * DYR;
-  const int M_here = min(DYR, p.M - m_base);
+  // ---- dy rows of this row half: ⌈M_here/8⌉ LDS-DMA instructions per stage (8 rows each), instruction i = wave + 8k
+  const int m_base = blockIdx.z * 128;
+  const int M_here = p.m_halves > 1 ? min(128, p.M - m_base) : p.M;
   const int nd = (M_here + 7) >> 3;
-  const int my_nd = nd > wave_s ? (nd - wave_s + NW - 1) / NW : 0;
-  static_assert(DYR / 8 <= 4 * NW, "at most four dy pieces per wave and stage");
+  const int my_nd = nd > wave_s ? (nd - wave_s + 7) >> 3 : 0;
   WwSrc dsrc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int i = wave_s + NW * k;
+    const int i = wave_s + 8 * k;
     const int r = ww_dma_row(i, lane), q = (lane ^ r) & 7;
     dsrc[k].p = r < M_here ? p.dy + ((long long)(m_base + r) * L + 4 * q) : nullptr;
     dsrc[k].bs = 0; dsrc[k].t = 4 * q;
@@ -877,7 +871,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tz_wgrad_kernel(TzParams p) {
     if (k >= my_nd || (p.exp & 4)) return;                 // wave-uniform
     const bool ok = dsrc[k].p != nullptr;
     const char* src = ok ? reinterpret_cast<const char*>(dsrc[k].p + (b * dy_bs + t0)) : zero16;
-    ww_dma16(src, tz_lds + slot * dslot_bytes + (wave_s + NW * k) * 1024);
+    ww_dma16(src, tz_lds + slot * dslot_bytes + (wave_s + 8 * k) * 1024);
   };
   auto issue_x1 = [&](int b, int t0, int slot) {
     if (wave_s >= TZ_CW || (p.exp & 4)) return;            // wave-uniform
@@ -953,22 +947,21 @@ __global__ __launch_bounds__(64 * NW, 2) void tz_wgrad_kernel(TzParams p) {
     // unit q = t & 15 of copy r = (t >> 4) & 7 of channel t >> 7: window samples 8q + r .. 8q + r + 7
     if (!(p.exp & 2)) {
       char* const dw = tz_lds + dslot * dslot_bytes;
-      // dy unit id = tid + NT·i: row id >> 2, unit id & 3
-      constexpr int DU = (DYR * 4 + NT - 1) / NT;
-      ww_f32x4 d[DU][2];
-      char* da[DU][2];
+      const int u = tid & 3, r0 = tid >> 2;
+      ww_f32x4 d[2][2];
+      char* da[2][2];
       const int dy_rows = nd << 3;
 #pragma unroll
-      for (int i = 0; i < DU; ++i) {
-        const int id = tid + NT * i, r = id >> 2, u = id & 3;
+      for (int i = 0; i < 2; ++i) {
+        const int r = r0 + 128 * i;
         da[i][0] = dw + ww_lds_off(r, 2 * u); da[i][1] = dw + ww_lds_off(r, 2 * u + 1);
         if (r < dy_rows) { d[i][0] = ww_lds_read16(da[i][0]); d[i][1] = ww_lds_read16(da[i][1]); }
       }
-      constexpr int XU = (128 * TZ_CW + NT - 1) / NT;       // copy units per thread (unit id = tid + NT·j)
+      constexpr int XU = (128 * TZ_CW + 511) / 512;         // copy units per thread (unit id = tid + 512·j)
       float xv[XU][8];
 #pragma unroll
       for (int j = 0; j < XU; ++j) {
-        const int id = tid + NT * j;
+        const int id = tid + 512 * j;
         if (id < 128 * TZ_CW) {
           const int xc = id >> 7, xr = (id >> 4) & 7, xq = id & 15;
           const char* src = xraw + (xslot * TZ_CW + xc) * TZ_XRAW + (8 * xq + xr) * 4;
@@ -978,8 +971,8 @@ __global__ __launch_bounds__(64 * NW, 2) void tz_wgrad_kernel(TzParams p) {
       }
       ww_lds_wait();
 #pragma unroll
-      for (int i = 0; i < DU; ++i) {
-        const int r = (tid + NT * i) >> 2;
+      for (int i = 0; i < 2; ++i) {
+        const int r = r0 + 128 * i;
         if (r < dy_rows) {
           ww_u32x4 h4, l4;
           ww_split8u(d[i][0], d[i][1], h4, l4);
@@ -988,7 +981,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tz_wgrad_kernel(TzParams p) {
       }
 #pragma unroll
       for (int j = 0; j < XU; ++j) {
-        const int id = tid + NT * j;
+        const int id = tid + 512 * j;
         if (id < 128 * TZ_CW) {
           const int xc = id >> 7, xr = (id >> 4) & 7, xq = id & 15;
           ww_u32x4 h4, l4;
@@ -1003,46 +996,39 @@ __global__ __launch_bounds__(64 * NW, 2) void tz_wgrad_kernel(TzParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    // ---- multiply.  The fragment reads of the second k-step are issued BEFORE the MFMAs of the first (two register sets): behind one
-    // another, reads (10 × 1 KiB per wave and k-step: 0.5 µs of LDS time per stage and CU) and MFMAs (0.96 µs) added up
+    // ---- multiply
     const char* const dsl = tz_lds + dslot * dslot_bytes;
-    ww_f32x4 araw[2][2][2], braw[2][3][2];
-    auto read_frags = [&](int ks) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      ww_f32x4 araw[2][2], braw[3][2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const char* ap = dsl + a_off + ((i * 32) << 7);
-        araw[ks][i][0] = ww_lds_read16(ap + pc[ks][0]);
-        araw[ks][i][1] = ww_lds_read16(ap + pc[ks][1]);
+        araw[i][0] = ww_lds_read16(ap + pc[ks][0]);
+        araw[i][1] = ww_lds_read16(ap + pc[ks][1]);
       }
 #pragma unroll
       for (int sb = 0; sb < 3; ++sb) {
         const char* bp = copies + b_off + ((2 * ks + 4 * sb) << 4);
-        braw[ks][sb][0] = ww_lds_read16(bp);
-        braw[ks][sb][1] = ww_lds_read16(bp + TZ_CW * 8 * TZ_CPB);
+        braw[sb][0] = ww_lds_read16(bp);
+        braw[sb][1] = ww_lds_read16(bp + TZ_CW * 8 * TZ_CPB);
       }
-    };
-    read_frags(0);
-    ww_lds_wait();
-    read_frags(1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 1) ww_lds_wait();
+      ww_lds_wait();
       issue_pos(3 * ks);
 #pragma unroll
       for (int sb = 0; sb < 3; ++sb) {
         if (sb < k_blocks && ch_live && !(p.exp & 1)) {    // wave-uniform
-          const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[ks][sb][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[ks][sb][1]);
+          const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[sb][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[sb][1]);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             if (wm * 2 + i >= m_blocks) break;             // wave-uniform
-            const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[ks][i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[ks][i][1]);
+            const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[i][1]);
             acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][sb], 0, 0, 0);
             acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][sb], 0, 0, 0);
             acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][sb], 0, 0, 0);
           }
         }
-        if (ks == 0) { if (sb < 2) issue_pos(1 + sb); }    // pos 0 | 1 2 | 3 | 4
+        if (ks == 0) { if (sb < 2) issue_pos(1 + sb); }    // pos 0 | 1 2 | 3 | 4 5(none)
         else if (sb == 0) issue_pos(4);
       }
     }
@@ -1080,19 +1066,18 @@ __global__ __launch_bounds__(256) void tz_reduce_kernel(TzParams p) {
   p.dw[((long long)m * p.C + c) * p.K + k] = (s0 + s1) + (s2 + s3);
 }
 
-// returns the row pairs per workgroup (1: the 8-wave few-row form, 2: the 4-wave form on row halves of 128)
 static int tz_geometry(int B, int L, int M, int C, int K, int pad, TzParams* p) {
-  const int MP = M <= 64 ? 1 : 2, TZ_CW = MP == 1 ? 8 : 2;
+  const int MP = M <= 64 ? 1 : 2, TZ_CW = 8 / MP;
+  p->m_halves = M > 128 ? 2 : 1;
   p->B = B; p->L = L; p->M = M; p->C = C; p->K = K;
   p->P4 = ((pad + 3) & ~3) + 4;
   p->off0 = p->P4 - pad;
-  p->m_halves = MP == 1 ? 1 : (M + 127) / 128;
   p->n_groups = (C + TZ_CW - 1) / TZ_CW;
   p->Kcols = p->n_groups * TZ_CW * 96;
   p->tiles_per_seq = L / WW_TT;
   p->n_tiles = B * p->tiles_per_seq;
   const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
-  int ks = (MP == 1 ? cus : 2 * cus) / (p->n_groups * p->m_halves);      // (two 4-wave workgroups per CU)
+  int ks = cus / (p->n_groups * p->m_halves);
   if (ks > p->n_tiles) ks = p->n_tiles;
   if (ks < 1) ks = 1;
   p->ksplit = ks;
@@ -1125,12 +1110,11 @@ extern "C" int fst_dense_tap_wgrad(const float* dy, const float* x, float* dw, f
   p.dy = dy; p.x = x; p.dw = dw; p.slab = workspace;
   static const int exp_env = getenv("FST_TZ_EXP") ? atoi(getenv("FST_TZ_EXP")) : 0;
   p.exp = exp_env;
-  const int cw = MP == 1 ? 8 : 2, dyr = 64 * MP;
-  const size_t lds = (size_t)WW_ND * dyr * 128 + 2 * cw * TZ_XRAW + (size_t)cw * 2 * 8 * TZ_CPB;
-  void (*fn)(TzParams) = MP == 1 ? tz_wgrad_kernel<8, 1> : tz_wgrad_kernel<4, 2>;
+  const int cw = 8 / MP;
+  const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + 2 * cw * TZ_XRAW + (size_t)cw * 2 * 8 * TZ_CPB;
+  void (*fn)(TzParams) = MP == 1 ? tz_wgrad_kernel<1> : tz_wgrad_kernel<2>;
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_dense_tap_wgrad")) return rc;
-  hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups, (unsigned)p.m_halves), dim3(64 * (MP == 1 ? 8 : 4)), lds,
-                     (hipStream_t)stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups, (unsigned)p.m_halves), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   hipLaunchKernelGGL(tz_reduce_kernel, dim3((unsigned)((p.C * 96 + 255) / 256), (unsigned)M), dim3(256), 0, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
