@@ -10,7 +10,7 @@ W=/tmp/prof_$TAG
 rm -rf $W; mkdir -p $W $OUT
 cd /tmp; export TMPDIR=/tmp
 export SETS=3            # tools/ww_time.py: one weight-gradient launch sums three operand sets, as the captured train step does
-for prog in wn_micro north_star_micro ww_time; do
+for prog in wn_micro north_star_micro ww_time tz_time; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $W/${prog}_fetch -- python3 $R/tools/$prog.py > $OUT/${TAG}_${prog}_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $W/${prog}_write -- python3 $R/tools/$prog.py > $OUT/${TAG}_${prog}_write.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv \
