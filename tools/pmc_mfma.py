@@ -14,7 +14,7 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         cnt[name][r["Counter_Name"]] += 1
 rows = []
 for k, c in acc.items():
-    if not k.startswith(("conv_", "wn_", "cpc_", "gate_", "bn_", "row_sum", "coupling")):
+    if not k.startswith(("conv_", "wn_", "tz_", "cpc_", "gate_", "bn_", "row_sum", "coupling")):
         continue
     n = max(cnt[k].values())
     m = {name: v / max(1, cnt[k][name]) for name, v in c.items()}

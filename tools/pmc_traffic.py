@@ -22,7 +22,7 @@ def load(d, counter):
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out, rows = {}, []
 for k in sorted(set(fetch) | set(write)):
-    if not k.startswith(("conv_", "gate_", "bn_", "pack", "row_sum", "cpc_", "coupling", "wn_")):
+    if not k.startswith(("conv_", "gate_", "bn_", "pack", "row_sum", "cpc_", "coupling", "wn_", "tz_", "noise_", "batch_sum", "logdet")):
         continue
     nf, sf = fetch.get(k, [0, 0.0]); nw, sw = write.get(k, [0, 0.0])
     rd = 2.0 * 1024.0 * sf / max(nf, 1); wr = 1024.0 * sw / max(nw, 1)
