@@ -53,6 +53,12 @@ def _wn_layer_f64(a, u0, in_w, cond_w, in_b, cond_b, rs_w, rs_b, dil):
     return gg, t, s, r
 
 
+# kernels that exist in the split-bf16 arithmetic only (the exact-f32 mode serves the same layers through the conv engine): run when
+# the suite's default arithmetic is the split one (not under FST_MATH=f32)
+bf3_only = pytest.mark.skipif(ops.MATH != "bf16x3", reason="split-bf16 kernel; FST_MATH=f32 routes around it")
+
+
+@bf3_only
 @pytest.mark.parametrize("L,dil,first,last", [(512, 1, True, False), (512, 128, False, False), (512, 128, False, True),
                                               (1024, 1, True, False), (1024, 128, False, True)])
 def test_fused_wn_layer_forward_full_batch(L, dil, first, last):
@@ -89,6 +95,7 @@ def test_fused_wn_layer_forward_full_batch(L, dil, first, last):
     assert_close(out_d, out, 2e-5, "out")
 
 
+@bf3_only
 @pytest.mark.parametrize("L,last", [(512, False), (512, True), (1024, False)])
 def test_fused_wn_layer_backward_full_batch(L, last):
     g = torch.Generator(device=DEV).manual_seed(L + int(last))
@@ -111,6 +118,7 @@ def test_fused_wn_layer_backward_full_batch(L, last):
     assert_close(sums, ws, 2e-5 * float(want.abs().sum(dim=(0, 2)).max()) / float(ws.abs().max()), "row sums of dg")
 
 
+@bf3_only
 @pytest.mark.parametrize("L,dil,res", [(512, 1, False), (512, 2, True), (512, 128, True),
                                        (1024, 1, True), (1024, 64, True), (1024, 128, True)])   # L=1024: 512 tiles on 256 CUs
 def test_fused_wn_layer_data_gradient_full_batch(L, dil, res):
@@ -201,6 +209,7 @@ def test_joint_step_gradients_at_batch_32(arithmetic):
     _check_step(*_step_both(js, tr, batch, (L // 8, L // 16)), tr, f"B=32 L={L} {arithmetic}", math=arithmetic)
 
 
+@bf3_only
 @pytest.mark.parametrize("n,h,Bq,L,dil", [(120, 25, 256, 512, 4), (120, 25, 256, 512, 128), (120, 25, 64, 1024, 16),
                                           (120, 25, 256, 512, 1), (120, 25, 256, 512, 2), (33, 31, 3, 64, 1), (8, 3, 2, 32, 2), (16, 5, 2, 64, 3),
                                           (8, 3, 3, 64, 4), (33, 31, 2, 96, 8), (127, 32, 2, 128, 4), (16, 16, 5, 32, 8),
@@ -238,6 +247,7 @@ def test_time_as_k_weight_gradient_kernels(n, h, Bq, L, dil):
         assert_close(dw[:, :, 0], torch.einsum("bmt,bct->mc", dy.double(), acts), 1e-4, f"res_skip dW (last={last})")
 
 
+@bf3_only
 @pytest.mark.parametrize("n,h,Bq,L,dil,n_sets", [(120, 25, 64, 512, 4, 3), (120, 25, 64, 512, 1, 2), (16, 5, 2, 64, 2, 3), (33, 31, 1, 32, 4, 3),
                                                  (8, 3, 1, 32, 8, 2)])      # (fewer tiles than workgroups per set)
 def test_time_as_k_weight_gradients_summed_over_operand_sets(n, h, Bq, L, dil, n_sets):

@@ -603,6 +603,10 @@ def test_logdet_and_inverse_transpose_kernel(n):
         assert float(ops.logdet(torch.zeros(n, n, device=DEV))) == float("-inf")   # an exactly zero pivot
 
 
+# kernels that exist in the split-bf16 arithmetic only: skipped when the whole suite runs under FST_MATH=f32
+bf3_only = pytest.mark.skipif(ops.MATH != "bf16x3", reason="split-bf16 kernel; FST_MATH=f32 routes around it")
+
+
 @pytest.mark.parametrize("B,C,L,device_ratios", [(256, 50, 512, False), (7, 6, 10, True), (33, 50, 64, True), (3, 5, 4, False)])
 def test_noise_transfer_kernels_vs_fp64_composition(B, C, L, device_ratios):
     """csrc/widgets.hip (ops.NoiseTransferFn) against the reference's composition (widgets.py:150-167) in fp64: output, the
@@ -638,6 +642,7 @@ def test_noise_transfer_kernels_vs_fp64_composition(B, C, L, device_ratios):
     assert torch.equal(out, out2) and torch.equal(avg_t, avg_t2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
 
 
+@bf3_only
 @pytest.mark.parametrize("M,N,K", [(256, 1024, 25600), (256, 25600, 1024), (3, 5, 32), (200, 130, 96), (33, 129, 64), (1, 1, 32)])
 def test_nt_gemm_vs_fp64(M, N, K):
     """fst_nt_gemm (C = A·Bmᵀ on the time-as-k kernel, K split into slabs added in a fixed order) against fp64; bit-identical twice."""
@@ -650,6 +655,7 @@ def test_nt_gemm_vs_fp64(M, N, K):
         ops.nt_gemm(A[:, : K - 1].contiguous(), Bm[:, : K - 1].contiguous())           # K % 32 != 0
 
 
+@bf3_only
 @pytest.mark.parametrize("Bq,D,O,ncls", [(256, 25600, 1024, 4), (7, 288, 96, 3)])
 def test_random_layer_fused_vs_composition(Bq, D, O, ncls):
     """ops.RandomLayerFn (the product, the 1/√O scale and the Hadamard product with p·R₁ in one GEMM epilogue) against the
@@ -669,6 +675,7 @@ def test_random_layer_fused_vs_composition(Bq, D, O, ncls):
     assert_close(gp, wp, 2e-5, "random layer dp")
 
 
+@bf3_only
 @pytest.mark.parametrize("M,C,ntaps,dil,pad,Bq,L", [(50, 225, 2, 1, 0, 256, 512), (50, 225, 2, 1, 0, 3, 64), (33, 70, 3, 4, 4, 2, 96),
                                                     (8, 64, 4, 1, 1, 2, 32), (256, 130, 3, 1, 1, 2, 64)])
 def test_few_tap_dense_weight_gradient_vs_fp64(M, C, ntaps, dil, pad, Bq, L, monkeypatch):
@@ -693,6 +700,7 @@ def test_few_tap_dense_weight_gradient_vs_fp64(M, C, ntaps, dil, pad, Bq, L, mon
         assert not spec.tap_wgrad_ok(Bq, L, x.clone(), dy)                      # no slack: the generic kernel serves it
 
 
+@bf3_only
 @pytest.mark.parametrize("M,C,K,pad,Bq,L", [(225, 25, 89, 44, 256, 512), (25, 1, 89, 44, 256, 512), (25, 50, 89, 44, 256, 512), (100, 9, 45, 22, 2, 64), (225, 25, 89, 44, 2, 64), (33, 3, 37, 18, 3, 96),
                                             (7, 2, 5, 2, 1, 32), (256, 5, 96, 47, 2, 64), (40, 4, 8, 3, 2, 128)])
 def test_dense_many_tap_weight_gradient_vs_fp64(M, C, K, pad, Bq, L):
