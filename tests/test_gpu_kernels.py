@@ -17,6 +17,8 @@ from feature_level_style_transfer_for_tsc_amd import ops
 from feature_level_style_transfer_for_tsc_amd.structure import generate_layer_parameter_list, out_channels, row_live_ranges
 
 DEV = "cuda"
+# kernels that exist in the split-bf16 arithmetic only: skipped when the whole suite runs under FST_MATH=f32
+bf3_only = pytest.mark.skipif(ops.MATH != "bf16x3", reason="split-bf16 kernel; FST_MATH=f32 routes around it")
 
 
 def ref_conv(x, w, bias, dil, pad_left, ntaps):
@@ -414,6 +416,7 @@ def test_batch_norm_global_batch_arguments_stay_inside_their_buffers():
     assert bool((dxbuf[:PAD] == CANARY).all()) and bool((dxbuf[PAD + n:] == CANARY).all())
 
 
+@bf3_only
 @pytest.mark.parametrize("n,h,B,L,dil,first,last", [
     (120, 25, 2, 512, 1, True, False), (120, 25, 2, 512, 8, False, False), (120, 25, 3, 512, 128, False, False),
     (120, 25, 2, 512, 128, False, True), (120, 25, 2, 200, 4, False, False),      # partial last tile (200 = 128 + 72)
@@ -460,6 +463,7 @@ def test_fused_wn_layer_forward(n, h, B, L, dil, first, last):
     assert torch.equal(ts2, ts_d) and torch.equal(out2, out_d)
 
 
+@bf3_only
 @pytest.mark.parametrize("n,B,L,last", [(120, 2, 512, False), (120, 3, 512, True), (120, 2, 200, False), (8, 3, 40, False),
                                         (8, 2, 40, True), (128, 1, 256, False), (33, 2, 132, False)])
 def test_fused_wn_layer_backward(n, B, L, last):
@@ -552,6 +556,7 @@ def test_two_step_lstm_matches_torch_lstm(B, H):
         assert_close(getattr(pt.model, name).grad, getattr(ref, name).grad, 2e-5, name)
 
 
+@bf3_only
 @pytest.mark.parametrize("n,h,B,L,dil,res", [(120, 25, 2, 512, 1, True), (120, 25, 2, 512, 2, True), (120, 25, 3, 512, 16, True),
                                              (120, 25, 2, 512, 128, False), (120, 25, 2, 1024, 64, True), (120, 25, 2, 200, 4, True),
                                              (8, 3, 3, 40, 2, True), (128, 32, 1, 256, 32, False), (33, 31, 2, 132, 8, True),
@@ -602,9 +607,6 @@ def test_logdet_and_inverse_transpose_kernel(n):
         assert sing == float("-inf") or sing != sing or sing < -25.0
         assert float(ops.logdet(torch.zeros(n, n, device=DEV))) == float("-inf")   # an exactly zero pivot
 
-
-# kernels that exist in the split-bf16 arithmetic only: skipped when the whole suite runs under FST_MATH=f32
-bf3_only = pytest.mark.skipif(ops.MATH != "bf16x3", reason="split-bf16 kernel; FST_MATH=f32 routes around it")
 
 
 @pytest.mark.parametrize("B,C,L,device_ratios", [(256, 50, 512, False), (7, 6, 10, True), (33, 50, 64, True), (3, 5, 4, False)])
