@@ -704,7 +704,8 @@ def test_few_tap_dense_weight_gradient_vs_fp64(M, C, ntaps, dil, pad, Bq, L, mon
 
 @bf3_only
 @pytest.mark.parametrize("M,C,K,pad,Bq,L", [(225, 25, 89, 44, 256, 512), (25, 1, 89, 44, 256, 512), (25, 50, 89, 44, 256, 512), (100, 9, 45, 22, 2, 64), (225, 25, 89, 44, 2, 64), (33, 3, 37, 18, 3, 96),
-                                            (7, 2, 5, 2, 1, 32), (256, 5, 96, 47, 2, 64), (40, 4, 8, 3, 2, 128)])
+                                            (7, 2, 5, 2, 1, 32), (256, 5, 96, 47, 2, 64), (40, 4, 8, 3, 2, 128),
+                                            (129, 3, 89, 44, 1, 32), (65, 5, 33, 0, 2, 64), (64, 9, 96, 95, 2, 32)])     # one-row second half; pad 0; pad K-1
 def test_dense_many_tap_weight_gradient_vs_fp64(M, C, K, pad, Bq, L):
     """fst_dense_tap_wgrad (the dense Q1 gradient of an omni-scale layer: every tap from eight pre-shifted copies of one staged window
     per channel) against an fp64 einsum — through ConvSpec.grad_w, which routes dense plans there; bit-identical twice."""
