@@ -36,7 +36,7 @@ struct CpcParams {
   long long s_i, s_b, s_c;
   const float* pred;   // [T][B][C] contiguous
   float* lse;          // [T][B]
-  float* nce_sum;      // scalar
+  float* nce_sum;      // [fst_cpc_nce_slots]: one partial sum per workgroup (per wave of the combine kernel), every slot written
   const float* gout;   // scalar upstream gradient of nce (device), bwd only
   float* denc;         // same strides as enc
   float* dpred;        // [T][B][C]
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
   }   // row blocks
   if (wave == 0 && p.n_panels == 1) {
     local += __shfl_xor(local, 32, 64);                    // the two halves hold different rows
-    if (lane == 0) atomicAdd(p.nce_sum, local);
+    // one slot per workgroup, summed by the caller in slot order: the loss is the same number in every run (a float atomic
+    // per workgroup added them in arrival order)
+    if (lane == 0) p.nce_sum[blockIdx.x * gridDim.y + blockIdx.y] = local;
   }
 }
 
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void cpc_combine_kernel(CpcParams p) {
     local += d - lse;
   }
   local = wave_sum_all(local);
-  if ((threadIdx.x & 63) == 0) atomicAdd(p.nce_sum, local);
+  if ((threadIdx.x & 63) == 0) p.nce_sum[blockIdx.x * 4 + (threadIdx.x >> 6)] = local;
 }
 
 // Backward on the matrix cores, one workgroup per step i (pred_i staged once), looping over 32-row blocks:
@@ -341,6 +343,25 @@ extern "C" int64_t fst_cpc_workspace_floats(int T, int B, int Bc) {
   return np > 1 ? (int64_t)T * B * np * 3 : 0;
 }
 
+// launch geometry of the forward, shared by fst_cpc_nce_slots: pred_i is staged once per workgroup; ~512 workgroups: the row blocks
+// of a step are split only as far as that needs
+static inline int cpc_fwd_ysplit(int T, int B) {
+  const int row_blocks = (B + 31) / 32;
+  int ysplit = (512 + T - 1) / T;
+  if (ysplit > row_blocks) ysplit = row_blocks;
+  return ysplit < 1 ? 1 : ysplit;
+}
+static inline long long cpc_combine_blocks(int T, int B) {
+  long long blocks = ((long long)T * B + 255) / 256;
+  return blocks > 1024 ? 1024 : blocks;
+}
+
+extern "C" int64_t fst_cpc_nce_slots(int T, int B, int Bc) {
+  if (T <= 0 || B <= 0 || Bc <= 0) return -1;
+  const int np = (Bc + CPC_PANEL - 1) / CPC_PANEL;
+  return np > 1 ? 4 * cpc_combine_blocks(T, B) : (int64_t)T * cpc_fwd_ysplit(T, B);
+}
+
 extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev,
                                const float* pred, int T, int B, int C, int Bc, int col_off, float* lse, float* nce_sum,
                                float* ws, void* stream) {
@@ -358,16 +379,11 @@ extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64
               p.n_panels);
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)cpc_fwd_kernel, "fst_cpc_nce_fwd")) return rc;
-  // pred_i is staged once per workgroup; ~512 workgroups: split the row blocks of a step only as far as that needs
-  const int row_blocks = (B + 31) / 32;
-  int ysplit = (512 + T - 1) / T;
-  if (ysplit > row_blocks) ysplit = row_blocks;
-  if (ysplit < 1) ysplit = 1;
+  const int ysplit = cpc_fwd_ysplit(T, B);
   hipLaunchKernelGGL(cpc_fwd_kernel, dim3(T, ysplit, p.n_panels), dim3(256), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   if (p.n_panels > 1) {
-    long long blocks = ((long long)T * B + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    const long long blocks = cpc_combine_blocks(T, B);
     hipLaunchKernelGGL(cpc_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     FST_LAUNCH_CHECK();
   }

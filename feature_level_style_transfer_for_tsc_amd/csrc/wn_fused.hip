@@ -321,7 +321,9 @@ __device__ __forceinline__ void wn_tile_to_acc(float (&v)[16], const float4 (&q)
 
 // Row sums of an accumulator tile on its way out (bias gradients: Σ_{b,t} of every row): after the transpose each lane
 // holds four consecutive samples of rows rrow + 8j, so a row's 32 samples are 8 lanes × float4 — three butterfly steps,
-// then one LDS float add per row and wave.  `rows` = LDS array indexed by the tile's absolute row.
+// then one LDS float add per row and wave.  `rows` = this WAVE's LDS array indexed by the tile's absolute row: one lane owns
+// an entry, so the add is a plain read-modify-write in program order and the workgroup's sum over its waves (taken by the
+// caller in wave order) is the same in every run — LDS float atomics from several waves were not.
 __device__ __forceinline__ void wn_tile_row_sums(const float* tile, float* rows, int row0, int rows_valid, int L, int t, int lane) {
   const int rrow = lane >> 3, c4 = (lane & 7) * 4;
   const bool t_ok = t + c4 < L;                          // samples beyond the sequence are not part of the sum (L % 4 == 0)
@@ -332,7 +334,7 @@ __device__ __forceinline__ void wn_tile_row_sums(const float* tile, float* rows,
     s4 += __shfl_xor(s4, 1, 64);
     s4 += __shfl_xor(s4, 2, 64);
     s4 += __shfl_xor(s4, 4, 64);
-    if ((lane & 7) == 0 && rrow + 8 * j < rows_valid) atomicAdd(rows + row0 + rrow + 8 * j, s4);
+    if ((lane & 7) == 0 && rrow + 8 * j < rows_valid) rows[row0 + rrow + 8 * j] += s4;
   }
 }
 
@@ -833,9 +835,11 @@ __global__ __launch_bounds__(256, WN_BWD_OCC) void wn_layer_bwd_kernel(WnBwdPara
   }
   __syncthreads();                                     // every wave is past its last fragment read: the ring becomes tiles
   float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
-  float* const rsum = reinterpret_cast<float*>(ldsb + 4 * WN_TILE_BYTES);      // [256] row sums of this workgroup's dg tile
+  float* const rsum = reinterpret_cast<float*>(ldsb + 4 * WN_TILE_BYTES);      // [4 waves][256] row sums of this workgroup's dg tile
+  float* const rsum_w = rsum + wave_s * 256;
   if (p.row_sums) {
-    rsum[tid] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) rsum[w * 256 + tid] = 0.f;
     __syncthreads();
   }
   float* const dg_b = p.dg + (long long)b * (2 * n) * L;
@@ -856,13 +860,14 @@ __global__ __launch_bounds__(256, WN_BWD_OCC) void wn_layer_bwd_kernel(WnBwdPara
       gs[r] = d * t * s * (1.f - s);
     }
     wn_store_tile<0>(gt, tile, dg_b + (long long)(blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
-    if (p.row_sums) wn_tile_row_sums(tile, rsum, blk * 32, rows_valid, L, tcol, lane);
+    if (p.row_sums) wn_tile_row_sums(tile, rsum_w, blk * 32, rows_valid, L, tcol, lane);
     wn_store_tile<0>(gs, tile, dg_b + (long long)(n + blk * 32) * L, nullptr, rows_valid, L, tcol, lane);
-    if (p.row_sums) wn_tile_row_sums(tile, rsum, n + blk * 32, rows_valid, L, tcol, lane);
+    if (p.row_sums) wn_tile_row_sums(tile, rsum_w, n + blk * 32, rows_valid, L, tcol, lane);
   }
   if (p.row_sums) {
     __syncthreads();
-    p.row_sums[(long long)tid * p.n_wg + wg] = rsum[tid];   // [256][n_wg]: the caller's sum runs over the contiguous axis
+    // [256][n_wg]: the caller's sum runs over the contiguous axis; waves added in a fixed order
+    p.row_sums[(long long)tid * p.n_wg + wg] = (rsum[tid] + rsum[256 + tid]) + (rsum[512 + tid] + rsum[768 + tid]);
   }
 }
 
@@ -1121,9 +1126,10 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
       first_slot = 1;
     }
     float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
-    float* const rsum = reinterpret_cast<float*>(ldsb + 8 * WN_TILE_BYTES);      // [128]
+    float* const rsum = reinterpret_cast<float*>(ldsb + 8 * WN_TILE_BYTES);      // [8 waves][128]
+    float* const rsum_w = rsum + wave_s * 128;
     if (p.row_sums) {
-      if (tid < 128) rsum[tid] = 0.f;
+      rsum[tid] = 0.f; rsum[512 + tid] = 0.f;
       __syncthreads();
     }
     // 5 × DG_NCB tiles straight from the accumulators; the bias-gradient row sums (when asked for) go through the
@@ -1138,12 +1144,17 @@ __global__ __launch_bounds__(512, 2) void wn_layer_dgrad_kernel(WnDgradParams p)
       if (p.row_sums && i < 4) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[i][cb][r];
-        wn_tile_row_sums(tile, rsum, i * 32, rows, L, tcol, lane);
+        wn_tile_row_sums(tile, rsum_w, i * 32, rows, L, tcol, lane);
       }
     }
     if (p.row_sums) {
       __syncthreads();
-      if (tid < 128) p.row_sums[(long long)tid * p.n_wg + wg] = rsum[tid];   // [128][n_wg]
+      if (tid < 128) {                                                        // [128][n_wg]; waves added in a fixed order
+        float s8 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s8 += rsum[w * 128 + tid];
+        p.row_sums[(long long)tid * p.n_wg + wg] = s8;
+      }
     }
   }
 }
@@ -1197,13 +1208,402 @@ extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t im
   const int NI = DG_A_BLOCKS * 2 + 2 * p.nblkw;
   FST_REQUIRE(((NI + 7) / 8) * (p.ns - 2) <= 16, "fst_wn_layer_dgrad: %d pieces per stage exceed the counted-wait table", NI);
   size_t lds_bytes = (size_t)p.ns * p.slot;
-  if (lds_bytes < 8 * WN_TILE_BYTES + 512) lds_bytes = 8 * WN_TILE_BYTES + 512;   // tiles + the row-sum array
+  if (lds_bytes < 8 * WN_TILE_BYTES + 4096) lds_bytes = 8 * WN_TILE_BYTES + 4096;   // tiles + the per-wave row-sum arrays
   if (int rc = fst_allow_full_lds((const void*)wn_layer_dgrad_kernel, "fst_wn_layer_dgrad")) return rc;
   // one persistent workgroup per CU; with a ring of one slot only (never: ns >= 2) the next tile could not start early
   int grid = p.n_wg;
   const int cus = fst_cu_count();
   if (cus > 0 && grid > cus && (size_t)2 * lds_bytes > 160 * 1024) grid = cus;
   hipLaunchKernelGGL(wn_layer_dgrad_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
+}
+
+// Accumulator layout <-> global memory with a UNIFORM row pointer and one 32-bit per-lane offset (voff = 4·half·L + l31, the same
+// for every tile a kernel touches): the accesses take the scalar-base form (global_load_dword v, v_off, s[base:base+1]), the row
+// term is scalar arithmetic and no 64-bit per-lane address is formed per row (sixteen of them per tile in wn_acc_load / _store:
+// the persistent kernel below has no registers for that).  `rows_t` = the tile's first row at its first column.
+__device__ __forceinline__ void wn_acc_load_s(f32x16& v, const float* rows_t, int rows_valid, int cols_valid, int L, unsigned voff, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const bool t_ok = l31 < cols_valid && rows_t != nullptr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2);
+    const float* rp = rows_t + (long long)row * L;
+    v[r] = (t_ok && row + 4 * half < rows_valid) ? rp[voff] : 0.f;
+  }
+}
+template <class V>
+__device__ __forceinline__ void wn_acc_store_s(const V& v, float* rows_t, int rows_valid, int cols_valid, int L, unsigned voff, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const bool t_ok = l31 < cols_valid;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2);
+    float* rp = rows_t + (long long)row * L;
+    if (t_ok && row + 4 * half < rows_valid) rp[voff] = v[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole backward of a WN stack in ONE persistent launch (sequences of up to 512 samples)
+//
+// fst_wn_layer_bwd + fst_wn_layer_dgrad, per layer, are two launches whose every workgroup walks the same phases at the same
+// time — operand loads (HBM), the GEMM (matrix cores), stores (HBM) — so the chip alternates between an idle matrix pipe and an
+// idle memory system, and d_a / dg / d_u0 make a round trip through HBM at every launch boundary.  With L <= 512 a 512-sample
+// tile IS a whole sequence: the dilated taps never look outside the tile, so the chain
+//     dacts = W_rsᵀ·[d_a ; d_out]  →  dg = gate'(t, s)·dacts  →  d_a += W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg        (layer nl−1 … 0)
+// of one batch element depends on nothing another workgroup produces.  One workgroup (8 waves × 64 samples) therefore walks
+// all layers of its batch element: what it writes in one phase (dg, d_a, d_u0) it reads back in the next while the lines are
+// still in its L2 / the Infinity Cache, the launch boundaries (2 per layer) are gone, and — nothing synchronising the
+// workgroups with each other — the CUs drift apart, so one CU's load / store phases run under other CUs' GEMM phases.
+// In GradNorm's partial passes (no weight gradients) dg and the intermediate d_a live in small scratch buffers that are rewritten
+// layer after layer and never have to reach HBM; the full pass keeps every layer's dg and d_a (the weight-gradient operands).
+//
+// Phase A = the body of wn_layer_bwd_kernel on a 512-sample tile (8 waves × 2 column blocks; the d_out stages first: they do
+// not depend on the phase before).  Phase B = the body of wn_layer_dgrad_kernel.  Global stores of one phase are read by the
+// next through LDS-DMA / loads of the SAME workgroup: s_waitcnt vmcnt(0) by every wave + a workgroup barrier orders them (one CU,
+// one L1: workgroup-scope coherence needs no cache maintenance).
+// ------------------------------------------------------------------------------------------------
+#define WS_MAXL 10
+#define WS_TN 512
+#define WS_NB (WS_TN / 32)                         // 32-sample column blocks of a phase-A window row group
+#define WS_GS (WS_NB * 1024 + 128)
+#define WS_SLOT_A (WN_BW_A + 2 * WS_GS)
+#define WS_LDS_A (3 * WS_SLOT_A)
+
+struct WnStackParams {
+  const float* ts[WS_MAXL];      // saved gate halves [B][2n][L] per layer
+  const char* img_b[WS_MAXL];    // fst_wn_pack_bwd images
+  const char* img_d[WS_MAXL];    // fst_wn_pack_dgrad images
+  float* dg[WS_MAXL];            // [B][2n][L] per layer (partial passes: one scratch tensor for all)
+  const float* da_in[WS_MAXL];   // cotangent of the layer's residual output [B][n][L]; null on the last layer
+  float* da_out[WS_MAXL];        // cotangent of the layer's input [B][n][L] (= da_in of the layer below)
+  float* rs_b[WS_MAXL];          // optional [256][B]: per-sequence Σ_t dg[row]
+  float* rs_d[WS_MAXL];          // optional [128][B]: per-sequence Σ_t da_out[row]
+  const float* d_out;            // [B][n][L]
+  float* d_u0;                   // [B][h][L] with batch stride d_u0_bs, accumulated in place
+  long long d_u0_bs;
+  int dil[WS_MAXL], nblkw[WS_MAXL], gsw[WS_MAXL], slot_d[WS_MAXL];
+  int nl, B, L, n, h, CH, CHK;
+};
+
+__global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by_value) {
+  // The per-layer tables are indexed with a run-time layer number: read through the kernarg segment they are scalar loads at a
+  // computed offset; indexing the by-value struct would make the compiler copy it to scratch (1 KiB per lane) or keep all of
+  // it in SGPRs (639 spilled).
+  const auto& p = *(const __attribute__((address_space(4))) WnStackParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)p_by_value;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_n0 = wave_s * 64;
+  const int L = p.L, n = p.n, CH = p.CH, CHK = p.CHK;
+  float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
+  float* const rsum = reinterpret_cast<float*>(ldsb + 8 * WN_TILE_BYTES);        // [8 waves][256]
+  float* const rsum_w = rsum + wave_s * 256;
+  const unsigned voff = (unsigned)(4 * half * L + l31);
+
+  for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    const float* const d_out_b = p.d_out + (long long)b * n * L;
+    for (int i = p.nl - 1; i >= 0; --i) {
+      const bool last = i == p.nl - 1;
+      // ============================================================ phase A: dg = gate'(t, s) · W_rsᵀ·[d_a ; d_out]
+      {
+        const char* const img = p.img_b[i];
+        const int S3 = (last ? 1 : 2) * CH;
+        const char* const zero16 = img + (long long)S3 * WN_BW_A;
+        const float* const ts_b = p.ts[i] + (long long)b * (2 * n) * L;
+        const float* const da_b = last ? nullptr : p.da_in[i] + (long long)b * n * L;
+        float* const dg_b = p.dg[i] + (long long)b * (2 * n) * L;
+        float* const rs_out = p.rs_b[i];
+        // stage k of the loop = image stage kk: the d_out stages first (nothing of the previous phase feeds them)
+        auto image_stage = [&](int k) { return last ? k : (k < CH ? CH + k : k - CH); };
+        auto issue = [&](int k, int slot) {
+          const int kk = image_stage(k);
+          char* const sl = ldsb + slot * WS_SLOT_A;
+          const char* asrc = img + (long long)kk * WN_BW_A;
+          const bool from_da = !last && kk < CH;
+          const int c = from_da ? kk : kk - (last ? 0 : CH);
+          const float* xb = (from_da ? da_b : d_out_b) + (long long)(16 * c) * L;
+          const int c_count = min(16, n - 16 * c);
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {                      // 8 pieces of A + 2 x 16 of B = 40 = five per wave
+            const int idx = wave_s + 8 * j;
+            if (idx < 8) {
+              __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+            } else {
+              const int bi = idx - 8;
+              const int gq = bi >> 4, m = bi & 15;
+              const int row = 8 * gq + (lane >> 3);
+              const int t = 32 * m + 4 * (lane & 7);
+              const bool ok = row < c_count && t < L;
+              const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
+              __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_BW_A + gq * WS_GS + m * 1024), 16, 0, 0);
+            }
+          }
+        };
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][cb][r] = 0.f;
+        // the gate halves of the first tile, requested before any LDS-DMA (the oldest vector-memory operations of the wave: every
+        // counted wait below covers them)
+        f32x16 tq, sq;
+        wn_acc_load_s(tq, ts_b + wave_n0, n, L - wave_n0, L, voff, lane);
+        wn_acc_load_s(sq, ts_b + (long long)n * L + wave_n0, n, L - wave_n0, L, voff, lane);
+        asm volatile("" ::: "memory");
+        issue(0, 0);
+        if (S3 > 1) issue(1, 1);
+        int slot = 0;
+        for (int k = 0; k < S3; ++k) {
+          if (k + 1 < S3) wn_wait_vmcnt<5>(); else wn_wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          if (k + 2 < S3) issue(k + 2, slot >= 1 ? slot - 1 : 2);
+          const char* base = ldsb + slot * WS_SLOT_A;
+          wn_bf16x8 bh[2], bl[2];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const int colx = wave_n0 + 32 * cb + l31;
+            const char* bp = base + WN_BW_A + half * WS_GS + (colx >> 5) * 1024 + (colx & 31) * 4;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
+            wn_u32x4 bh4, bl4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              unsigned hh, ll;
+              wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
+              bh4[j] = hh; bl4[j] = ll;
+            }
+            bh[cb] = __builtin_bit_cast(wn_bf16x8, bh4); bl[cb] = __builtin_bit_cast(wn_bf16x8, bl4);
+          }
+#pragma unroll
+          for (int mb = 0; mb < 4; ++mb) {
+            const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
+            const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cb], acc[mb][cb], 0, 0, 0);
+              acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cb], acc[mb][cb], 0, 0, 0);
+              acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cb], acc[mb][cb], 0, 0, 0);
+            }
+          }
+          slot = slot == 2 ? 0 : slot + 1;
+        }
+        if (rs_out) {
+          __syncthreads();                               // every wave is past its last fragment read: the ring becomes tiles
+#pragma unroll
+          for (int w = 0; w < 4; ++w) rsum[w * 512 + tid] = 0.f;
+          __syncthreads();
+        }
+        // gate, eight (row block, column block) tiles per wave; the next tile's gate halves are in flight while one is gated
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int blk = q >> 1, cb = q & 1;
+          const int rows_valid = n - blk * 32, tcol = wave_n0 + 32 * cb;
+          const f32x16 tv = tq, sv = sq;
+          if (q < 7) {
+            const int nb = (q + 1) >> 1, nc = (q + 1) & 1;
+            wn_acc_load_s(tq, ts_b + (long long)(nb * 32) * L + wave_n0 + 32 * nc, n - nb * 32, L - wave_n0 - 32 * nc, L, voff, lane);
+            wn_acc_load_s(sq, ts_b + (long long)(n + nb * 32) * L + wave_n0 + 32 * nc, n - nb * 32, L - wave_n0 - 32 * nc, L, voff, lane);
+          }
+          float gt[16], gs[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[blk][cb][r], t = tv[r], s = sv[r];
+            gt[r] = d * s * (1.f - t * t);
+            gs[r] = d * t * s * (1.f - s);
+          }
+          wn_acc_store_s(gt, dg_b + (long long)(blk * 32) * L + tcol, rows_valid, L - tcol, L, voff, lane);
+          wn_acc_store_s(gs, dg_b + (long long)(n + blk * 32) * L + tcol, rows_valid, L - tcol, L, voff, lane);
+          if (rs_out) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gt[r];
+            wn_tile_row_sums(tile, rsum_w, blk * 32, rows_valid, L, tcol, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gs[r];
+            wn_tile_row_sums(tile, rsum_w, n + blk * 32, rows_valid, L, tcol, lane);
+          }
+        }
+        if (rs_out) {
+          __syncthreads();
+          if (tid < 256) {
+            float s8 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s8 += rsum[w * 256 + tid];
+            rs_out[(long long)tid * p.B + b] = s8;            // [256][B]
+          }
+        }
+        wn_wait_vmcnt<0>();                                  // this wave's dg stores have reached L2 ...
+        __syncthreads();                                     // ... and so have everyone's: phase B may fetch them; the ring is free
+      }
+      // ============================================================ phase B: d_a = d_a_in + W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg
+      {
+        const int dil = p.dil[i], nblkw = p.nblkw[i], gsw = p.gsw[i], slotb = p.slot_d[i];
+        const char* const img = p.img_d[i];
+        const char* const zero16 = img + (long long)CHK * DG_A_BYTES;
+        const float* const dgr = p.dg[i] + (long long)b * (2 * n) * L;
+        const float* const da_b = last ? nullptr : p.da_in[i] + (long long)b * n * L;
+        float* const dan_b = p.da_out[i] + (long long)b * n * L;
+        float* const du_b = p.d_u0 + (long long)b * p.d_u0_bs;
+        float* const rs_out = p.rs_d[i];
+        const int NI = DG_A_BLOCKS * 2 + 2 * nblkw;
+        const int sub = (0 - dil) & 3;
+        const int w4 = (0 - dil) & ~3;
+        auto issue = [&](int c, int slot) {
+          char* const sl = ldsb + slot * slotb;
+          const char* asrc = img + (long long)c * DG_A_BYTES;
+          const float* xb = dgr + (long long)(16 * c) * L;
+          const int c_count = min(16, 2 * n - 16 * c);
+          for (int idx = wave_s; idx < NI; idx += 8) {
+            if (idx < 2 * DG_A_BLOCKS) {
+              __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+            } else {
+              const int bi = idx - 2 * DG_A_BLOCKS;
+              const int gq = bi >= nblkw ? 1 : 0, m = bi - gq * nblkw;
+              const int row = 8 * gq + (lane >> 3);
+              const int t = w4 + 32 * m + 4 * (lane & 7);
+              const bool ok = row < c_count && t >= 0 && t < L;
+              const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
+              __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + DG_A_BYTES + gq * gsw + m * 1024), 16, 0, 0);
+            }
+          }
+        };
+        f32x16 acc[5][DG_NCB];
+#pragma unroll
+        for (int mb = 0; mb < 5; ++mb)
+#pragma unroll
+          for (int cb = 0; cb < DG_NCB; ++cb) {
+            const float* src = mb < 4 ? (da_b ? da_b + (long long)(mb * 32) * L : nullptr) : du_b;
+            const int rows = mb < 4 ? (da_b ? n - mb * 32 : 0) : p.h;
+            wn_acc_load_s(acc[mb][cb], src ? src + wave_n0 + 32 * cb : nullptr, rows, L - wave_n0 - 32 * cb, L, voff, lane);
+          }
+        asm volatile("" ::: "memory");
+        issue(0, 0);                                         // two ring slots: one stage in flight while one is multiplied
+        int slot = 0;
+        for (int c = 0; c < CHK; ++c) {
+          wn_wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          if (c + 1 < CHK) issue(c + 1, slot ^ 1);
+          const char* base = ldsb + slot * slotb;
+#pragma unroll
+          for (int tap = 0; tap < 3; ++tap) {
+            wn_bf16x8 bh[DG_NCB], bl[DG_NCB];
+#pragma unroll
+            for (int cb = 0; cb < DG_NCB; ++cb) {
+              const int colx = wave_n0 + 32 * cb + l31 + (2 - tap) * dil + sub;
+              const char* bp = base + DG_A_BYTES + half * gsw + (colx >> 5) * 1024 + (colx & 31) * 4;
+              float v8[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v8[j] = *reinterpret_cast<const float*>(bp + j * 128);
+              wn_u32x4 bh4, bl4;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                unsigned hh, ll;
+                wn_split_pair(v8[2 * j], v8[2 * j + 1], hh, ll);
+                bh4[j] = hh; bl4[j] = ll;
+              }
+              bh[cb] = __builtin_bit_cast(wn_bf16x8, bh4); bl[cb] = __builtin_bit_cast(wn_bf16x8, bl4);
+            }
+            const char* ab = base + (tap == 0 ? 0 : (tap == 1 ? 4 : 9)) * 2048;
+#pragma unroll
+            for (int mb = 0; mb < 5; ++mb) {
+              if (mb == 4 && tap != 1) continue;
+              const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + lane * 16);
+              const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(ab + mb * 2048 + 1024 + lane * 16);
+#pragma unroll
+              for (int cb = 0; cb < DG_NCB; ++cb) {
+                acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cb], acc[mb][cb], 0, 0, 0);
+                acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cb], acc[mb][cb], 0, 0, 0);
+                acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cb], acc[mb][cb], 0, 0, 0);
+              }
+            }
+          }
+          slot ^= 1;
+        }
+        __syncthreads();                                     // every wave is past its last fragment read: the ring is free
+        if (rs_out) {
+          rsum[tid] = 0.f; rsum[512 + tid] = 0.f;
+          __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < 5 * DG_NCB; ++k) {
+          const int ib = k / DG_NCB, cb = k % DG_NCB, tcol = wave_n0 + 32 * cb;
+          float* dst = ib < 4 ? dan_b + (long long)(ib * 32) * L : du_b;
+          const int rows = ib < 4 ? n - ib * 32 : p.h;
+          wn_acc_store_s(acc[ib][cb], dst + tcol, rows, L - tcol, L, voff, lane);
+          if (rs_out && ib < 4) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[ib][cb][r];
+            wn_tile_row_sums(tile, rsum + wave_s * 128, ib * 32, rows, L, tcol, lane);
+          }
+        }
+        if (rs_out) {
+          __syncthreads();
+          if (tid < 128) {
+            float s8 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s8 += rsum[w * 128 + tid];
+            rs_out[(long long)tid * p.B + b] = s8;            // [128][B]
+          }
+        }
+        wn_wait_vmcnt<0>();                                  // d_a / d_u0 of this layer are in L2 before the next phase A reads them
+        __syncthreads();
+      }
+    }
+  }
+}
+
+// 1 when fst_wn_stack_bwd serves a WN stack of nl layers on sequences of L samples (dilations 1, 2, 4, ... as the reference's WN)
+extern "C" int fst_wn_stack_bwd_ok(int n, int h, int L, int nl) {
+  if (!(n > 0 && n <= 128 && h > 0 && h <= 32 && L > 0 && L <= WS_TN && L % 4 == 0 && nl > 0 && nl <= WS_MAXL)) return 0;
+  for (int i = 0; i < nl; ++i)
+    if (i >= 20 || !fst_wn_dgrad_fits(n, h, 1 << i)) return 0;
+  return 1;
+}
+
+extern "C" int fst_wn_stack_bwd(const float* const* ts, const void* const* img_b, const void* const* img_d, float* const* dg,
+                                const float* const* da_in, float* const* da_out, float* const* rs_b, float* const* rs_d,
+                                const float* d_out, float* d_u0, int64_t d_u0_bs, int nl, int B, int L, int n, int h,
+                                int64_t numel_a, void* stream) {
+  FST_REQUIRE(ts && img_b && img_d && dg && da_in && da_out && d_out && d_u0, "fst_wn_stack_bwd: null table");
+  FST_REQUIRE(fst_wn_stack_bwd_ok(n, h, L, nl), "fst_wn_stack_bwd: not served: n=%d h=%d L=%d nl=%d (needs n <= 128, h <= 32, "
+              "L <= 512, L %% 4 == 0, nl <= %d)", n, h, L, nl, WS_MAXL);
+  FST_REQUIRE(B > 0 && (long long)B * n * L == (long long)numel_a,
+              "fst_wn_stack_bwd: B*n*L does not match the element count %lld of the [B][n][L] tensors", (long long)numel_a);
+  FST_REQUIRE(d_u0_bs >= (int64_t)h * L && d_u0_bs % 4 == 0,
+              "fst_wn_stack_bwd: d_u0 batch stride %lld (needs >= h*L = %lld and a multiple of 4)", (long long)d_u0_bs, (long long)h * L);
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  WnStackParams p;
+  size_t lds_bytes = WS_LDS_A;
+  for (int i = 0; i < nl; ++i) {
+    const bool last = i == nl - 1;
+    FST_REQUIRE(ts[i] && img_b[i] && img_d[i] && dg[i] && da_out[i] && (last || da_in[i]), "fst_wn_stack_bwd: null operand of layer %d", i);
+    FST_REQUIRE(al16(ts[i]) && al16(img_b[i]) && al16(img_d[i]) && al16(dg[i]) && al16(da_in[i]) && al16(da_out[i]),
+                "fst_wn_stack_bwd: operands of layer %d must be 16-byte aligned", i);
+    FST_REQUIRE((rs_b == nullptr) == (rs_d == nullptr), "fst_wn_stack_bwd: row sums of both kinds or of neither");
+    p.ts[i] = ts[i]; p.img_b[i] = static_cast<const char*>(img_b[i]); p.img_d[i] = static_cast<const char*>(img_d[i]);
+    p.dg[i] = dg[i]; p.da_in[i] = last ? nullptr : da_in[i]; p.da_out[i] = da_out[i];
+    p.rs_b[i] = rs_b ? rs_b[i] : nullptr; p.rs_d[i] = rs_d ? rs_d[i] : nullptr;
+    p.dil[i] = 1 << i;
+    wn_dgrad_geometry(p.dil[i], &p.nblkw[i], &p.gsw[i], &p.slot_d[i]);
+    if ((size_t)2 * p.slot_d[i] > lds_bytes) lds_bytes = (size_t)2 * p.slot_d[i];
+  }
+  FST_REQUIRE(al16(d_out) && al16(d_u0), "fst_wn_stack_bwd: d_out / d_u0 must be 16-byte aligned");
+  if (lds_bytes < 8 * WN_TILE_BYTES + 8192) lds_bytes = 8 * WN_TILE_BYTES + 8192;
+  FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_wn_stack_bwd: %zu bytes of LDS", lds_bytes);
+  p.d_out = d_out; p.d_u0 = d_u0; p.d_u0_bs = d_u0_bs;
+  p.nl = nl; p.B = B; p.L = L; p.n = n; p.h = h; p.CH = wn_ch(n); p.CHK = (2 * n + 15) / 16;
+  if (int rc = fst_allow_full_lds((const void*)wn_stack_bwd_kernel, "fst_wn_stack_bwd")) return rc;
+  const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
+  const int grid = B < cus ? B : cus;                    // one resident workgroup per CU walks its batch elements
+  hipLaunchKernelGGL(wn_stack_bwd_kernel, dim3((unsigned)grid), dim3(512), lds_bytes, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
   return 0;
 }

@@ -119,10 +119,14 @@ __device__ __forceinline__ void ww_lds_zero4(char* p) {
 }
 // One LDS-DMA piece as inline asm too: with the builtin the same pass put s_waitcnt vmcnt(0) in front of the address arithmetic of
 // every piece but the first once the issues were spread between the MFMAs (each issue then waited for all earlier pieces to land).
-// M0 carries the wave-uniform LDS byte address; the 64 lanes' 16 bytes land at M0 + 16·lane.
+// M0 carries the wave-uniform LDS byte address; the 64 lanes' 16 bytes land at M0 + 16·lane.  M0 is a register the compiler
+// reserves for itself (it may not appear in a clobber list: "may not be preserved"), so the block saves it and puts it back:
+// the instruction reads M0 when it issues, the restore right behind it is safe.
 __device__ __forceinline__ void ww_dma16(const char* gsrc, char* lds_dst) {
   const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)lds_dst);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(addr) : "memory", "m0");
+  unsigned saved_m0;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(saved_m0) : "v"(gsrc), "s"(addr) : "memory");
 }
 __device__ __forceinline__ void ww_lds_wait() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -1731,14 +1731,15 @@ class CPCNceFn(torch.autograd.Function):
         assert t0_dev is None or (t0_dev.dtype == torch.int32 and t0_dev.is_cuda)
         assert t0_host + T <= L
         lse = torch.empty(T, B, device=feat.device, dtype=torch.float32)
-        acc = torch.zeros((), device=feat.device, dtype=torch.float32)
+        # one partial sum per workgroup, added here in slot order (deterministic; float atomics into one scalar were not)
+        acc = torch.empty(lib.fst_cpc_nce_slots(T, B, Bc), device=feat.device, dtype=torch.float32)
         n_ws = lib.fst_cpc_workspace_floats(T, B, Bc)                          # > 256 negatives: per-panel softmax statistics
         ws = torch.empty(n_ws, device=feat.device, dtype=torch.float32) if n_ws else None
         check(lib.fst_cpc_nce_fwd(feat.data_ptr() + 4 * t0_host, 1, C * L, L, ptr(t0_dev), ptr(pred), T, B, C, Bc, col_off,
                                   ptr(lse), ptr(acc), ptr(ws), stream_ptr()), "fst_cpc_nce_fwd")
         ctx.save_for_backward(feat, pred, lse)
         ctx.t0_host, ctx.t0_dev, ctx.T, ctx.col_off = t0_host, t0_dev, T, col_off
-        return acc * (-1.0 / (B * T))
+        return acc.sum() * (-1.0 / (B * T))
 
     @staticmethod
     def backward(ctx, g):

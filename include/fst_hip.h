@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 8
+#define FST_ABI_VERSION 9
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -353,10 +353,13 @@ int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, con
  * fst_cpc_workspace_floats(T, B, Bc) floats (0 for Bc <= 256) for the per-panel softmax statistics, and the backward
  * accumulates denc across panels with fp32 atomics (the caller zero-fills denc — it must anyway outside [t0, t0+T)). */
 int64_t fst_cpc_workspace_floats(int T, int B, int Bc);
+/* nce_sum is an array of fst_cpc_nce_slots(T, B, Bc) partial sums, one per workgroup, every slot written (no zero fill): the
+ * caller adds them in slot order, so the loss is bit-identical from run to run (ABI v9; a zeroed scalar fed by float atomics before). */
+int64_t fst_cpc_nce_slots(int T, int B, int Bc);
 int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
                     const float* pred /* [T][Bc][C] */, int T, int B, int C,
                     int Bc /* columns = negatives; = B on one GPU */, int col_off /* column of row 0's positive */,
-                    float* lse /* [T][B] */, float* nce_sum /* scalar, zeroed */, float* workspace /* NULL if Bc <= 256 */,
+                    float* lse /* [T][B] */, float* nce_sum /* [fst_cpc_nce_slots] partial sums */, float* workspace /* NULL if Bc <= 256 */,
                     void* stream);
 int fst_cpc_nce_bwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
                     const float* pred, const float* lse, int T, int B, int C, int Bc, int col_off, const float* gout,

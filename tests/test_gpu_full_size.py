@@ -172,15 +172,22 @@ def test_weight_gradients_full_batch(L, dil, arithmetic):
         assert_close(dws[:, :, 0], torch.einsum("bmt,bct->mc", d_a.double(), u0.double()), 1e-4, "start dW")
 
 
-def test_forward_only_joint_step_full_batch_vs_oracle():
-    """B=256, L=512 (the bench configuration): the forward of the whole joint step — nine losses, the three logit tensors,
-    the transferred feature — against the CPU oracle from identical seeded state.  Reference: train_and_test.py:547-603."""
-    L, Bf, seed = 512, 256, 4242
-    js = R.build_joint_step(L, 1, L, 1, 4, 4, seed=seed, dropout_p=0.0, zero_end=False)
-    tr = _trainer_from(js, L, L, 4)
+@pytest.mark.parametrize("L,Bf,C_in,ncls,ts", [(512, 256, 1, 4, (61, 17)),        # configs[1]: the bench configuration
+                                               (1024, 256, 1, 4, (200, 75)),     # configs[4]: the per-GPU shape of the 8-GPU run
+                                               (5000, 32, 9, 6, (100, 37))])     # configs[3] at its bench batch
+def test_forward_only_joint_step_full_batch_vs_oracle(L, Bf, C_in, ncls, ts):
+    """The forward of the WHOLE joint step at the batch sizes the bench rows are quoted on — nine losses, the three logit
+    tensors, the target feature and the transferred feature — against the CPU oracle from identical seeded state
+    (train_and_test.py:547-603).  At L=1024 / B=256 this is the only place the omni-scale window kernel, BatchNorm's moments
+    over 262 144 samples per channel, CPC with T=512 steps and the K=51 200 random-layer GEMM meet an independent reference at
+    full batch; at 9 × 5000 / B=32 the 1 GB random matrix and 2500 CPC steps do."""
+    seed = 4242 + L
+    js = R.build_joint_step(L, C_in, L, C_in, ncls, ncls, seed=seed, dropout_p=0.0, zero_end=False)
+    cfg = fst.JointConfig(L_t=L, C_in_t=C_in, L_s=L, C_in_s=C_in, n_class_t=ncls, n_class_s=ncls, dropout_p=0.0)
+    tr = fst.JointTrainer(cfg, DEV)
+    tr.load_params({k: {n: t.detach() for n, t in v.items()} for k, v in js.m.items()}, js.mats)
     gen = torch.Generator().manual_seed(seed + 1)
-    (x_t, y_t), (x_s, y_s) = _pair(gen, Bf, 1, L, 4), _pair(gen, Bf, 1, L, 4)
-    ts = (61, 17)
+    (x_t, y_t), (x_s, y_s) = _pair(gen, Bf, C_in, L, ncls), _pair(gen, Bf, C_in, L, ncls)
     with ops.pack_cache(), tr.m["nf"].shared_fold(), tr.m["cpc"].shared_stack():
         Ld, aux = tr.forward_losses(x_t.to(DEV), y_t.to(DEV), x_s.to(DEV), y_s.to(DEV), ts)
     Ld = {k: float(v) for k, v in Ld.items()}
@@ -193,7 +200,7 @@ def test_forward_only_joint_step_full_batch_vs_oracle():
         a, b = Ld[k], float(Lo[k])
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
     for k in ("logit_t", "logit_s", "logit_s2t", "feat_t", "feat_s2t"):
-        close(aux[k], aux_o[k], 1e-4, f"B=256 forward {k}")
+        close(aux[k], aux_o[k], 1e-4, f"B={Bf} L={L} forward {k}")
 
 
 def test_joint_step_gradients_at_batch_32(arithmetic):

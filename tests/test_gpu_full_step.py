@@ -70,14 +70,9 @@ def _head_unit_branches(record=None, impose=None, flips=None):
             assert worst <= FLIP_BOUND, (f"layer {layer_no[0]}: {int(diff.sum())} unit(s) take the other branch on the device with "
                                          f"|x|/max|x| up to {worst:.2e} — not a rounding-level disagreement")
 
-    def synced(x):
-        # record mode sees only the layers that call F.relu on the device (heads, dimension unification); impose mode consumes one
-        # recorded mask per ReLU of the oracle — the convolutional ones included, recorded from the fused BatchNorm+ReLU launches
-        return True
-
+    # record mode sees the layers that call F.relu on the device (heads, dimension unification) plus — through the wrappers
+    # below — the ReLUs fused into the BatchNorm launches; impose mode consumes one recorded mask per ReLU of the oracle
     def relu(x, inplace=False):
-        if not synced(x):
-            return relu0(x, inplace)
         if record is not None:
             record.append((x > 0).cpu())
             return relu0(x, inplace)
@@ -87,8 +82,6 @@ def _head_unit_branches(record=None, impose=None, flips=None):
         return x * m.to(x.dtype)
 
     def leaky(x, negative_slope=0.01, inplace=False):
-        if not synced(x):
-            return leaky0(x, negative_slope, inplace)
         if record is not None:
             record.append((x > 0).cpu())
             return leaky0(x, negative_slope, inplace)
@@ -303,17 +296,27 @@ def test_full_batch_graph_replay_equals_eager_step():
     snap = tr.snapshot()
     rep = {k: v.clone() for k, v in tr.replay(*args, (31, 77)).items()}
     after_graph = tr.snapshot()
+    # run-to-run: a second replay from the same state reproduces the first bit for bit — every reported tensor and every
+    # tensor the step mutates (parameters, BatchNorm buffers, optimiser moments): no float atomics are left on the step's path
+    tr.restore(snap)
+    rep2 = tr.replay(*args, (31, 77))
+    for k, v in rep.items():
+        assert torch.equal(rep2[k], v), f"two replays differ in {k}: {float((rep2[k].double() - v.double()).abs().max()):.3e}"
+    again = tr.snapshot()["t"]
+    differing = [k for k, v in after_graph["t"].items() if not torch.equal(again[k], v)]
+    assert not differing, f"two replays leave different state in {len(differing)} tensors, e.g. {differing[:5]}"
     tr.restore(snap)
     eager = tr.step(*args, epoch=0, t_samples=(31, 77))
     for k in LOSSES:
         a, b = float(rep[k]), float(eager[k])
-        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
-    # logit_s2t: the eval-mode classifier on the transferred features, after 11 optimisation steps from random
-    # initialisation its running statistics are far from the batch's and the logits are ~1e8: fp32-atomic sum order (the
-    # two runs differ in the last bits) is amplified to ~1e-3 there
-    for k in ("logit_t", "logit_s", "logit_s2t", "w_t", "w_s", "norms_t", "norms_s"):
-        close(rep[k], eager[k], 3e-3 if k == "logit_s2t" else (5e-4 if k.startswith("logit") else 1e-4 if k.startswith("w_") else 1e-3),
-              f"graph vs eager {k}")                              # logit_t / logit_s: 2e-4 seen (same atomics, one step earlier)
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (k, a, b)
+    # Two runs of the product from the same state: every launch of the step is deterministic (BatchNorm moments, bias-gradient
+    # row sums and the CPC loss are fixed-order sums, the K-split GEMMs reduce slabs: tools/determinism_probe.py shows
+    # eager/eager and graph/graph bit-identical), and the captured step issues the same launches as the eager one, so the gate
+    # is north_star's 1e-4 with a wide margin — measured: 0 on every forward quantity, 1e-7 on parameters after the update
+    # (the graph reads the CPC start index / NoiseTransfer ratios from device scalars).
+    for k in ("logit_t", "logit_s", "logit_s2t", "feat_t", "feat_s2t", "w_t", "w_s", "norms_t", "norms_s"):
+        close(rep[k], eager[k], 1e-5, f"graph vs eager {k}")
     after_eager = tr.snapshot()
     # weights whose gradient is real (not rounding noise in front of a BatchNorm): RMSprop's first-step size is
     # lr*g/sqrt(0.01 g^2) = 10*lr whatever |g|, so equal signs give equal steps
