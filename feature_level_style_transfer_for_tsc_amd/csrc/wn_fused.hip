@@ -26,6 +26,7 @@
 // chunk, fed from a 16-byte block of ones), GEMM 2 sees acts[n] = 1 — so n < 128 is required (one spare K row).
 // Two workgroups share a CU (79 KB of LDS, ≤ 256 registers): one's t,s store burst is the other's MFMA time.
 #include "fst_common.h"
+#include <type_traits>
 
 typedef __bf16 wn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wn_bf16x2 __attribute__((ext_vector_type(2)));
@@ -1219,29 +1220,65 @@ extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t im
   return 0;
 }
 
-// Accumulator layout <-> global memory with a UNIFORM row pointer and one 32-bit per-lane offset (voff = 4·half·L + l31, the same
-// for every tile a kernel touches): the accesses take the scalar-base form (global_load_dword v, v_off, s[base:base+1]), the row
-// term is scalar arithmetic and no 64-bit per-lane address is formed per row (sixteen of them per tile in wn_acc_load / _store:
-// the persistent kernel below has no registers for that).  `rows_t` = the tile's first row at its first column.
-__device__ __forceinline__ void wn_acc_load_s(f32x16& v, const float* rows_t, int rows_valid, int cols_valid, int L, unsigned voff, int lane) {
-  const int half = lane >> 5, l31 = lane & 31;
-  const bool t_ok = l31 < cols_valid && rows_t != nullptr;
+// Accumulator layout <-> global memory through raw buffer instructions: one descriptor per [rows][L] matrix of a batch element,
+// ONE per-lane byte offset for the whole kernel (vlane = (4·half·L + l31)·4) and the row / column term of every access in the
+// instruction's scalar offset — an access is one buffer_load/store_dword with no VALU work, no 64-bit address and no exec mask
+// (wn_acc_load / _store form sixteen per-lane addresses per tile; the persistent kernel below has no registers for that).
+// Columns beyond the sequence: the lane's offset is pushed out of the descriptor's range (loads return 0, stores are dropped by
+// the hardware's range check).  Rows beyond the matrix: wave-uniform tests per register (the two lane halves of a register
+// are 4 rows apart: a register whose upper half only is out of range goes through the half-masked offset).
+#define WS_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x40000000, 0x00020000);
+}
+struct WsLane { unsigned vo, vo_lo; };     // offsets of a lane whose column exists: both halves / lower half only
+__device__ __forceinline__ WsLane ws_lane(unsigned vlane, int tcol, int L, int lane) {
+  WsLane w;
+  w.vo = tcol + (lane & 31) < L ? vlane : WS_OOB;
+  w.vo_lo = lane < 32 ? w.vo : WS_OOB;
+  return w;
+}
+// tile = rows row0 .. row0+31 (rv of them exist, rv may be <= 0 or >= 32), columns tcol .. tcol+31 of the matrix behind `rs`
+// (The scalar offsets are formed from an opaque copy of L: loop-invariant otherwise, the compiler computes those of every tile of
+// the kernel ahead of the layer loop and keeps — i.e. spills — hundreds of them.)
+__device__ __forceinline__ int ws_opaque(int x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+__device__ __forceinline__ void ws_acc_load(f32x16& v, __amdgpu_buffer_rsrc_t rs, const WsLane w, int row0, int tcol, int rv, int L) {
+  L = ws_opaque(L);
+  rv = ws_opaque(rv);
+  const int sbase = (row0 * L + tcol) * 4;
+  if (rv >= 32) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2);
-    const float* rp = rows_t + (long long)row * L;
-    v[r] = (t_ok && row + 4 * half < rows_valid) ? rp[voff] : 0.f;
+    for (int r = 0; r < 16; ++r)
+      v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      float x = 0.f;
+      if (row < rv) x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, 0));
+      v[r] = x;
+    }
   }
 }
 template <class V>
-__device__ __forceinline__ void wn_acc_store_s(const V& v, float* rows_t, int rows_valid, int cols_valid, int L, unsigned voff, int lane) {
-  const int half = lane >> 5, l31 = lane & 31;
-  const bool t_ok = l31 < cols_valid;
+__device__ __forceinline__ void ws_acc_store(const V& v, __amdgpu_buffer_rsrc_t rs, const WsLane w, int row0, int tcol, int rv, int L) {
+  L = ws_opaque(L);
+  rv = ws_opaque(rv);
+  const int sbase = (row0 * L + tcol) * 4;
+  if (rv >= 32) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2);
-    float* rp = rows_t + (long long)row * L;
-    if (t_ok && row + 4 * half < rows_valid) rp[voff] = v[r];
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, 0);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      if (row < rv)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, 0);
+    }
   }
 }
 
@@ -1301,70 +1338,82 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_n0 = wave_s * 64;
   const int L = p.L, n = p.n, CH = p.CH, CHK = p.CHK;
-  float* const tile = reinterpret_cast<float*>(ldsb + wave_s * WN_TILE_BYTES);
-  float* const rsum = reinterpret_cast<float*>(ldsb + 8 * WN_TILE_BYTES);        // [8 waves][256]
+  // the epilogues' transpose tiles and row-sum arrays sit above the first two phase-A ring slots: the next layer's first two
+  // stages stream into those while a phase-B epilogue is still using the tiles
+  float* const tile = reinterpret_cast<float*>(ldsb + 2 * WS_SLOT_A + wave_s * WN_TILE_BYTES);
+  float* const rsum = reinterpret_cast<float*>(ldsb + 2 * WS_SLOT_A + 8 * WN_TILE_BYTES);        // [8 waves][256]
   float* const rsum_w = rsum + wave_s * 256;
-  const unsigned voff = (unsigned)(4 * half * L + l31);
+  const unsigned vlane = (unsigned)(4 * half * L + l31) * 4u;
+  const WsLane wl0 = ws_lane(vlane, wave_n0, L, lane), wl1 = ws_lane(vlane, wave_n0 + 32, L, lane);
 
+  // one stage of phase A of layer i into ring slot `slot`; stage k of the loop = image stage kk: the d_out stages first (nothing
+  // of the previous phase feeds them, so the first two are issued under the previous layer's last stores)
+  auto issue_a = [&](int i, int b, int k, int slot) {
+    const bool last = i == p.nl - 1;
+    const char* const img = p.img_b[i];
+    const int S3 = (last ? 1 : 2) * CH;
+    const char* const zero16 = img + (long long)S3 * WN_BW_A;
+    const int kk = last ? k : (k < CH ? CH + k : k - CH);
+    char* const sl = ldsb + slot * WS_SLOT_A;
+    const char* asrc = img + (long long)kk * WN_BW_A;
+    const bool from_da = !last && kk < CH;
+    const int c = from_da ? kk : kk - (last ? 0 : CH);
+    const float* xb = (from_da ? p.da_in[i] : p.d_out) + ((long long)b * n + 16 * c) * L;
+    const int c_count = min(16, n - 16 * c);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {                          // 8 pieces of A + 2 x 16 of B = 40 = five per wave
+      const int idx = wave_s + 8 * j;
+      if (idx < 8) {
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
+      } else {
+        const int bi = idx - 8;
+        const int gq = bi >> 4, m = bi & 15;
+        const int row = 8 * gq + (lane >> 3);
+        const int t = 32 * m + 4 * (lane & 7);
+        const bool ok = row < c_count && t < L;
+        const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
+        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_BW_A + gq * WS_GS + m * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  WN_SUMS;
+  WN_T(tw0);
+  int primed = 0;                                          // how many of the first two phase-A stages of the layer at hand are already in flight
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
-    const float* const d_out_b = p.d_out + (long long)b * n * L;
     for (int i = p.nl - 1; i >= 0; --i) {
       const bool last = i == p.nl - 1;
+      // accumulators of both phases: phase A multiplies into [0..3] (its dacts rows); as the gate consumes a tile, that tile's
+      // registers receive the d_a tile phase B starts from, so those loads fly under the rest of the gate epilogue
+      f32x16 acc[5][2];
+      const float* const da_b = last ? nullptr : p.da_in[i] + (long long)b * n * L;
+      const __amdgpu_buffer_rsrc_t da_r = ws_rsrc(da_b);
       // ============================================================ phase A: dg = gate'(t, s) · W_rsᵀ·[d_a ; d_out]
       {
-        const char* const img = p.img_b[i];
         const int S3 = (last ? 1 : 2) * CH;
-        const char* const zero16 = img + (long long)S3 * WN_BW_A;
-        const float* const ts_b = p.ts[i] + (long long)b * (2 * n) * L;
-        const float* const da_b = last ? nullptr : p.da_in[i] + (long long)b * n * L;
-        float* const dg_b = p.dg[i] + (long long)b * (2 * n) * L;
+        // the tanh | sigmoid halves are two [n][L] matrices
+        const __amdgpu_buffer_rsrc_t ts_t = ws_rsrc(p.ts[i] + (long long)b * (2 * n) * L);
+        const __amdgpu_buffer_rsrc_t ts_s = ws_rsrc(p.ts[i] + ((long long)b * 2 + 1) * n * L);
+        const __amdgpu_buffer_rsrc_t dg_t = ws_rsrc(p.dg[i] + (long long)b * (2 * n) * L);
+        const __amdgpu_buffer_rsrc_t dg_s = ws_rsrc(p.dg[i] + ((long long)b * 2 + 1) * n * L);
         float* const rs_out = p.rs_b[i];
-        // stage k of the loop = image stage kk: the d_out stages first (nothing of the previous phase feeds them)
-        auto image_stage = [&](int k) { return last ? k : (k < CH ? CH + k : k - CH); };
-        auto issue = [&](int k, int slot) {
-          const int kk = image_stage(k);
-          char* const sl = ldsb + slot * WS_SLOT_A;
-          const char* asrc = img + (long long)kk * WN_BW_A;
-          const bool from_da = !last && kk < CH;
-          const int c = from_da ? kk : kk - (last ? 0 : CH);
-          const float* xb = (from_da ? da_b : d_out_b) + (long long)(16 * c) * L;
-          const int c_count = min(16, n - 16 * c);
-#pragma unroll
-          for (int j = 0; j < 5; ++j) {                      // 8 pieces of A + 2 x 16 of B = 40 = five per wave
-            const int idx = wave_s + 8 * j;
-            if (idx < 8) {
-              __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
-            } else {
-              const int bi = idx - 8;
-              const int gq = bi >> 4, m = bi & 15;
-              const int row = 8 * gq + (lane >> 3);
-              const int t = 32 * m + 4 * (lane & 7);
-              const bool ok = row < c_count && t < L;
-              const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
-              __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_BW_A + gq * WS_GS + m * 1024), 16, 0, 0);
-            }
-          }
-        };
-        f32x16 acc[4][2];
+        WN_T(ta0);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
           for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][cb][r] = 0.f;
-        // the gate halves of the first tile, requested before any LDS-DMA (the oldest vector-memory operations of the wave: every
-        // counted wait below covers them)
-        f32x16 tq, sq;
-        wn_acc_load_s(tq, ts_b + wave_n0, n, L - wave_n0, L, voff, lane);
-        wn_acc_load_s(sq, ts_b + (long long)n * L + wave_n0, n, L - wave_n0, L, voff, lane);
-        asm volatile("" ::: "memory");
-        issue(0, 0);
-        if (S3 > 1) issue(1, 1);
+        if (primed < 1) issue_a(i, b, 0, 0);
+        if (primed < 2 && S3 > 1) issue_a(i, b, 1, 1);
+        primed = 0;
         int slot = 0;
+        WN_T(ta1);
+        WN_ACC(0, ta0, ta1);                             // phase A: ring priming (issue)
         for (int k = 0; k < S3; ++k) {
           if (k + 1 < S3) wn_wait_vmcnt<5>(); else wn_wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
-          if (k + 2 < S3) issue(k + 2, slot >= 1 ? slot - 1 : 2);
+          if (k + 2 < S3) issue_a(i, b, k + 2, slot >= 1 ? slot - 1 : 2);
           const char* base = ldsb + slot * WS_SLOT_A;
           wn_bf16x8 bh[2], bl[2];
 #pragma unroll
@@ -1396,32 +1445,41 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
           }
           slot = slot == 2 ? 0 : slot + 1;
         }
+        WN_T(ta2);
+        WN_ACC(1, ta1, ta2);                             // phase A: GEMM loop
+        // gate, eight (row block, column block) tiles per wave, the gate halves of the next tile in flight while one is gated
+        f32x16 tq[2], sq[2];
+        ws_acc_load(tq[0], ts_t, wl0, 0, wave_n0, n, L);
+        ws_acc_load(sq[0], ts_s, wl0, 0, wave_n0, n, L);
         if (rs_out) {
           __syncthreads();                               // every wave is past its last fragment read: the ring becomes tiles
 #pragma unroll
           for (int w = 0; w < 4; ++w) rsum[w * 512 + tid] = 0.f;
           __syncthreads();
         }
-        // gate, eight (row block, column block) tiles per wave; the next tile's gate halves are in flight while one is gated
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int blk = q >> 1, cb = q & 1;
+        // (written as eight calls of a generic lambda: the optimizer refused to unroll the loop form, and the tile arrays then
+        // lived in scratch memory)
+        auto gate_tile = [&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int blk = q >> 1, cb = q & 1;
           const int rows_valid = n - blk * 32, tcol = wave_n0 + 32 * cb;
-          const f32x16 tv = tq, sv = sq;
+          __builtin_amdgcn_sched_barrier(0);              // (tile by tile: a scheduler that hoists the loads of later tiles runs out of registers)
           if (q < 7) {
-            const int nb = (q + 1) >> 1, nc = (q + 1) & 1;
-            wn_acc_load_s(tq, ts_b + (long long)(nb * 32) * L + wave_n0 + 32 * nc, n - nb * 32, L - wave_n0 - 32 * nc, L, voff, lane);
-            wn_acc_load_s(sq, ts_b + (long long)(n + nb * 32) * L + wave_n0 + 32 * nc, n - nb * 32, L - wave_n0 - 32 * nc, L, voff, lane);
+            constexpr int nb = (q + 1) >> 1, nc = (q + 1) & 1;
+            ws_acc_load(tq[(q + 1) & 1], ts_t, nc ? wl1 : wl0, nb * 32, wave_n0 + 32 * nc, n - nb * 32, L);
+            ws_acc_load(sq[(q + 1) & 1], ts_s, nc ? wl1 : wl0, nb * 32, wave_n0 + 32 * nc, n - nb * 32, L);
           }
           float gt[16], gs[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float d = acc[blk][cb][r], t = tv[r], s = sv[r];
+            const float d = acc[blk][cb][r], t = tq[q & 1][r], s = sq[q & 1][r];
             gt[r] = d * s * (1.f - t * t);
             gs[r] = d * t * s * (1.f - s);
           }
-          wn_acc_store_s(gt, dg_b + (long long)(blk * 32) * L + tcol, rows_valid, L - tcol, L, voff, lane);
-          wn_acc_store_s(gs, dg_b + (long long)(n + blk * 32) * L + tcol, rows_valid, L - tcol, L, voff, lane);
+          // the tile's registers are free: phase B's starting value (the residual cotangent; zeros when there is none)
+          ws_acc_load(acc[blk][cb], da_r, cb ? wl1 : wl0, blk * 32, tcol, da_b ? rows_valid : 0, L);
+          ws_acc_store(gt, dg_t, cb ? wl1 : wl0, blk * 32, tcol, rows_valid, L);
+          ws_acc_store(gs, dg_s, cb ? wl1 : wl0, blk * 32, tcol, rows_valid, L);
           if (rs_out) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gt[r];
@@ -1430,7 +1488,11 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
             for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gs[r];
             wn_tile_row_sums(tile, rsum_w, n + blk * 32, rows_valid, L, tcol, lane);
           }
-        }
+        };
+        gate_tile(std::integral_constant<int, 0>{}); gate_tile(std::integral_constant<int, 1>{});
+        gate_tile(std::integral_constant<int, 2>{}); gate_tile(std::integral_constant<int, 3>{});
+        gate_tile(std::integral_constant<int, 4>{}); gate_tile(std::integral_constant<int, 5>{});
+        gate_tile(std::integral_constant<int, 6>{}); gate_tile(std::integral_constant<int, 7>{});
         if (rs_out) {
           __syncthreads();
           if (tid < 256) {
@@ -1440,8 +1502,12 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
             rs_out[(long long)tid * p.B + b] = s8;            // [256][B]
           }
         }
+        WN_T(ta3);
+        WN_ACC(2, ta2, ta3);                             // phase A: gate epilogue (loads, stores, row sums: issue + waits)
         wn_wait_vmcnt<0>();                                  // this wave's dg stores have reached L2 ...
         __syncthreads();                                     // ... and so have everyone's: phase B may fetch them; the ring is free
+        WN_T(ta4);
+        WN_ACC(3, ta3, ta4);                             // phase A -> B: store drain + barrier
       }
       // ============================================================ phase B: d_a = d_a_in + W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg
       {
@@ -1449,9 +1515,8 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
         const char* const img = p.img_d[i];
         const char* const zero16 = img + (long long)CHK * DG_A_BYTES;
         const float* const dgr = p.dg[i] + (long long)b * (2 * n) * L;
-        const float* const da_b = last ? nullptr : p.da_in[i] + (long long)b * n * L;
-        float* const dan_b = p.da_out[i] + (long long)b * n * L;
-        float* const du_b = p.d_u0 + (long long)b * p.d_u0_bs;
+        const __amdgpu_buffer_rsrc_t dan_r = ws_rsrc(p.da_out[i] + (long long)b * n * L);
+        const __amdgpu_buffer_rsrc_t du_r = ws_rsrc(p.d_u0 + (long long)b * p.d_u0_bs);
         float* const rs_out = p.rs_d[i];
         const int NI = DG_A_BLOCKS * 2 + 2 * nblkw;
         const int sub = (0 - dil) & 3;
@@ -1475,18 +1540,15 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
             }
           }
         };
-        f32x16 acc[5][DG_NCB];
-#pragma unroll
-        for (int mb = 0; mb < 5; ++mb)
-#pragma unroll
-          for (int cb = 0; cb < DG_NCB; ++cb) {
-            const float* src = mb < 4 ? (da_b ? da_b + (long long)(mb * 32) * L : nullptr) : du_b;
-            const int rows = mb < 4 ? (da_b ? n - mb * 32 : 0) : p.h;
-            wn_acc_load_s(acc[mb][cb], src ? src + wave_n0 + 32 * cb : nullptr, rows, L - wave_n0 - 32 * cb, L, voff, lane);
-          }
+        WN_T(tb0);
+        // the d_a tiles were requested as phase A's gate released their registers; the conditioning rows here
+        ws_acc_load(acc[4][0], du_r, wl0, 0, wave_n0, p.h, L);
+        ws_acc_load(acc[4][1], du_r, wl1, 0, wave_n0 + 32, p.h, L);
         asm volatile("" ::: "memory");
         issue(0, 0);                                         // two ring slots: one stage in flight while one is multiplied
         int slot = 0;
+        WN_T(tb1);
+        WN_ACC(4, tb0, tb1);                             // phase B: accumulator loads + first stage (issue)
         for (int c = 0; c < CHK; ++c) {
           wn_wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
@@ -1527,7 +1589,22 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
           }
           slot ^= 1;
         }
+        WN_T(tb2);
+        WN_ACC(5, tb1, tb2);                             // phase B: GEMM loop
         __syncthreads();                                     // every wave is past its last fragment read: the ring is free
+        // the d_out stages of the next phase A (the layer below, or the top layer of this workgroup's next sequence) depend on
+        // nothing this phase stores: into ring slots 0 and 1 now, under the stores below
+        {
+          const int ni = i > 0 ? i - 1 : p.nl - 1, nb = i > 0 ? b : b + (int)gridDim.x;
+          if (nb < p.B) {
+            issue_a(ni, nb, 0, 0);
+            primed = 1;
+            if (CH > 1) {                                    // stage 1 is a d_out stage too (with one chunk per source it is the d_a stage)
+              issue_a(ni, nb, 1, 1);
+              primed = 2;
+            }
+          }
+        }
         if (rs_out) {
           rsum[tid] = 0.f; rsum[512 + tid] = 0.f;
           __syncthreads();
@@ -1535,9 +1612,9 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
 #pragma unroll
         for (int k = 0; k < 5 * DG_NCB; ++k) {
           const int ib = k / DG_NCB, cb = k % DG_NCB, tcol = wave_n0 + 32 * cb;
-          float* dst = ib < 4 ? dan_b + (long long)(ib * 32) * L : du_b;
           const int rows = ib < 4 ? n - ib * 32 : p.h;
-          wn_acc_store_s(acc[ib][cb], dst + tcol, rows, L - tcol, L, voff, lane);
+          if (ib < 4) ws_acc_store(acc[ib][cb], dan_r, cb ? wl1 : wl0, ib * 32, tcol, rows, L);
+          else ws_acc_store(acc[ib][cb], du_r, cb ? wl1 : wl0, 0, tcol, rows, L);
           if (rs_out && ib < 4) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[ib][cb][r];
@@ -1553,11 +1630,20 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
             rs_out[(long long)tid * p.B + b] = s8;            // [128][B]
           }
         }
-        wn_wait_vmcnt<0>();                                  // d_a / d_u0 of this layer are in L2 before the next phase A reads them
+        WN_T(tb3);
+        WN_ACC(6, tb2, tb3);                             // phase B: epilogue stores (issue)
+        // d_a / d_u0 of this layer must be in L2 before the d_a stages / the starting values of the next layer fetch them: the
+        // wait below also retires the two primed stages (issued before the stores: vmcnt is in order)
+        wn_wait_vmcnt<0>();
         __syncthreads();
+        WN_T(tb4);
+        WN_ACC(7, tb3, tb4);                             // phase B -> A: store drain + barrier
       }
     }
   }
+  WN_T(tw1);
+  WN_ACC(9, tw0, tw1);
+  WN_FLUSH;
 }
 
 // 1 when fst_wn_stack_bwd serves a WN stack of nl layers on sequences of L samples (dilations 1, 2, 4, ... as the reference's WN)
@@ -1596,7 +1682,7 @@ extern "C" int fst_wn_stack_bwd(const float* const* ts, const void* const* img_b
     if ((size_t)2 * p.slot_d[i] > lds_bytes) lds_bytes = (size_t)2 * p.slot_d[i];
   }
   FST_REQUIRE(al16(d_out) && al16(d_u0), "fst_wn_stack_bwd: d_out / d_u0 must be 16-byte aligned");
-  if (lds_bytes < 8 * WN_TILE_BYTES + 8192) lds_bytes = 8 * WN_TILE_BYTES + 8192;
+  if (lds_bytes < 2 * WS_SLOT_A + 8 * WN_TILE_BYTES + 8192) lds_bytes = 2 * WS_SLOT_A + 8 * WN_TILE_BYTES + 8192;   // tiles + row sums above two phase-A slots
   FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_wn_stack_bwd: %zu bytes of LDS", lds_bytes);
   p.d_out = d_out; p.d_u0 = d_u0; p.d_u0_bs = d_u0_bs;
   p.nl = nl; p.B = B; p.L = L; p.n = n; p.h = h; p.CH = wn_ch(n); p.CHK = (2 * n + 15) / 16;

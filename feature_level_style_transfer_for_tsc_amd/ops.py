@@ -1254,6 +1254,57 @@ def wn_layer_dgrad(dg: Tensor, img: Tensor, d_a: Optional[Tensor], d_u0: Tensor,
     return d_a_new, part.sum(dim=1)[:n]
 
 
+def wn_stack_bwd_ok(n: int, h: int, L: int, nl: int) -> bool:
+    """Whether the whole backward of a WN stack runs as ONE persistent launch (fst_wn_stack_bwd: sequences of up to 512 samples —
+    a 512-sample tile is then the whole sequence and one workgroup walks every layer of its batch element)."""
+    if os.environ.get("FST_WN_STACK", "1") == "0":                                # diagnostics: one launch pair per layer
+        return False
+    return bool(_lib.load().fst_wn_stack_bwd_ok(n, h, L, nl))
+
+
+def _ptr_table(ts: Sequence[Optional[Tensor]]):
+    arr = (ctypes.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def wn_stack_bwd(ts_list: Sequence[Tensor], imgs_b: Sequence[Tensor], imgs_d: Sequence[Tensor], dgs: Sequence[Tensor],
+                 da_in: Sequence[Optional[Tensor]], da_out: Sequence[Tensor], d_out: Tensor, d_u0: Tensor, n: int, h: int,
+                 part_b: Optional[Tensor] = None, part_d: Optional[Tensor] = None) -> None:
+    """Layers nl-1 .. 0 of a WN stack's backward in one launch (csrc/wn_fused.hip, fst_wn_stack_bwd): per layer
+    dg = gate'(t, s)·W_rsᵀ·[da_in ; d_out],  da_out = da_in + W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg.  ``dgs`` / ``da_out`` entries may
+    alias scratch tensors when nothing reads them afterwards (GradNorm's partial passes).  ``part_b`` [nl, 256, B] / ``part_d``
+    [nl, 128, B]: per-sequence row sums of dg / da_out (the bias gradients), both or neither."""
+    lib = _lib.load()
+    nl = len(ts_list)
+    B, _, L = d_out.shape
+    numel = _same_numel(d_out, *[t for t in da_out], *[t for t in da_in if t is not None])
+    for t in list(ts_list) + list(dgs):
+        if t.numel() != 2 * numel or not t.is_contiguous():
+            raise ValueError("wn_stack_bwd: ts / dg must be contiguous [B, 2n, L]")
+    d_u0_bs, _ = _ncl(d_u0, "d_u0")
+    if tuple(d_u0.shape) != (B, h, L):
+        raise ValueError(f"wn_stack_bwd: d_u0 must be [B, h, L] = {(B, h, L)}, got {tuple(d_u0.shape)}")
+    if (part_b is None) != (part_d is None):
+        raise ValueError("wn_stack_bwd: row sums of both kinds or of neither")
+    if part_b is not None and (tuple(part_b.shape) != (nl, 256, B) or tuple(part_d.shape) != (nl, 128, B)
+                               or not (part_b.is_contiguous() and part_d.is_contiguous())):
+        raise ValueError("wn_stack_bwd: row-sum slabs must be contiguous [nl, 256, B] and [nl, 128, B]")
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    rs_b = None if part_b is None else _ptr_table([part_b[i] for i in range(nl)])
+    rs_d = None if part_d is None else _ptr_table([part_d[i] for i in range(nl)])
+    check(lib.fst_wn_stack_bwd(_ptr_table(ts_list), _ptr_table(imgs_b), _ptr_table(imgs_d), _ptr_table(dgs), _ptr_table(da_in),
+                               _ptr_table(da_out), rs_b, rs_d, ptr(d_out), ptr(d_u0), d_u0_bs, nl, B, L, n, h, numel, stream_ptr()),
+          "fst_wn_stack_bwd")
+    if t0 is not None:
+        # per layer: GEMM 3 (K = 2n, n on the last layer) + the data gradient; bytes: d_out, t,s read, d_u0 in/out; dg and d_a are
+        # counted as written once and read once (what the per-layer launches move through HBM)
+        flops = 2.0 * B * L * (n * (2 * n * nl - n) + nl * 2 * n * (3 * n + h))
+        rows = nl * (n + 2 * n + 2 * h + 2 * 2 * n + 2 * n)
+        KERNEL_TIMER.end("wn_stack_bwd_kernel", t0, flops, 4.0 * B * L * rows)
+
+
 def _wn_forward(specs: WNSpecs, u0: Tensor, flat: Tensor):
     """Forward of the WN stack (WNFn's docstring).  Returns (o, fused, the tensors ``_wn_backward`` needs)."""
     lib = _lib.load()
@@ -1362,9 +1413,46 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
     fused_dg = [fused and wn_dgrad_ok(n, h, 2 ** i) and os.environ.get("FST_WN_DGRAD", "fused") == "fused" for i in range(nl)]
     # bias-gradient row sums: every fused launch leaves per-workgroup partials in its slab; ONE reduction per kind adds the
     # slabs of all layers straight into the flat gradient's segments (instead of one reduction launch per layer and kind)
-    part_b = wn_bwd_partials(nl, B, L, dev) if (need_w and fused_bwd) else None
-    part_d = wn_dgrad_partials(nl, B, L, dev) if (need_w and all(fused_dg)) else None
-    for i in reversed(range(nl)):
+    stack = fused_bwd and all(fused_dg) and wn_stack_bwd_ok(n, h, L, nl)
+    if stack:
+        # ---- every layer in ONE persistent launch.  The full pass keeps each layer's dg and d_a (operands of the weight
+        # gradients); a partial pass (GradNorm: no weight gradients) rewrites one dg and two d_a scratch tensors layer after layer
+        imgs_b = [wn_pack_bwd(rs_w[i], n, i == nl - 1) for i in range(nl)]
+        imgs_d = [wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h) for i in range(nl)]
+        new = lambda c: torch.empty(B, c, L, device=dev, dtype=torch.float32)
+        if need_w:
+            dgs = [new(2 * n) for _ in range(nl)]
+            da_out = [new(n) for _ in range(nl)]
+        else:
+            dg1, pp = new(2 * n), (new(n), new(n))
+            dgs = [dg1] * nl
+            da_out = [pp[i & 1] for i in range(nl)]
+        da_in = [da_out[i + 1] if i + 1 < nl else None for i in range(nl)]
+        part_b = torch.empty(nl, 256, B, device=dev, dtype=torch.float32) if need_w else None
+        part_d = torch.empty(nl, 128, B, device=dev, dtype=torch.float32) if need_w else None
+        wn_stack_bwd(ts_list, imgs_b, imgs_d, dgs, da_in, da_out, d_out, d_u0, n, h, part_b, part_d)
+        if need_w:
+            for i in range(nl):
+                last = i == nl - 1
+                if defer_rs[i]:
+                    pool.add((1, i), (da_in[i], d_out, ts_list[i]))
+                elif wn_wgrad_ok(1, B, L, n, h, 2 ** i):
+                    wn_wgrad_rs(da_in[i], d_out, ts_list[i], g_rs_w[i], last, n)
+                elif last:
+                    S.rs[i].grad_w(ts_list[i][:, :n], None, d_out, x0_mul_off=n * L, out0=g_rs_w[i])
+                else:
+                    S.rs[i].grad_w(ts_list[i][:, :n], None, da_in[i], d_out, msplit=n, x0_mul_off=n * L, out0=g_rs_w[i])
+                if defer_in[i]:
+                    pool.add((0, i), (dgs[i], a_list[i], u0))
+                elif wn_wgrad_ok(0, B, L, n, h, 2 ** i, a_list[i]):
+                    wn_wgrad_in(dgs[i], a_list[i], u0, g_in_w[i], g_cond_w[2 * n * i: 2 * n * (i + 1)], n, h, 2 ** i)
+                else:
+                    S.ins[i].grad_w(a_list[i], u0, dgs[i], out0=g_in_w[i], out1=g_cond_w[2 * n * i: 2 * n * (i + 1)])
+        d_a, d_a_sum = da_out[0], None
+    else:
+        part_b = wn_bwd_partials(nl, B, L, dev) if (need_w and fused_bwd) else None
+        part_d = wn_dgrad_partials(nl, B, L, dev) if (need_w and all(fused_dg)) else None
+    for i in (() if stack else reversed(range(nl))):
         last = i == nl - 1
         # ---- through res_skip: rs rows [0,n) carried d_a, rows [n,2n) (or all n rows when last) carried d_out
         dacts = None if fused_bwd else torch.empty(B, n, L, device=dev, dtype=torch.float32)

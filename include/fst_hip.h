@@ -258,6 +258,22 @@ int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, 
                        float* row_sums /* optional [128][B·⌈L/512⌉]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
                        int B, int L, int n, int h, int dil, int64_t numel_a, int64_t d_u0_bs, void* stream);
 
+/* The whole backward of a WN stack — fst_wn_layer_bwd and fst_wn_layer_dgrad of every layer, top layer first — as ONE persistent
+ * launch (the backward autograd derives for the loop of Simplified_NF_WaveGlow.py:104-121), for sequences of up to 512 samples:
+ * a 512-sample tile is then a whole sequence, the dilated taps never leave it, and one workgroup walks all layers of its batch
+ * element; what a phase writes (dg, d_a, d_u0) the next reads back from L2 / the Infinity Cache, and the CUs are not held in
+ * step by launch boundaries.  All tables are HOST arrays of nl entries (layer 0 = dilation 1 first; layer i has dilation 2^i):
+ *   ts[i] the saved gate halves; img_b[i] / img_d[i] the fst_wn_pack_bwd / fst_wn_pack_dgrad images; dg[i] [B][2n][L] written
+ *   (entries may alias each other when nothing reads dg afterwards); da_in[i] the cotangent of layer i's residual output
+ *   (ignored for i = nl-1) and da_out[i] the cotangent of its input, written — da_out[i] is da_in[i-1]; rs_b[i] / rs_d[i]
+ *   optional [256][B] / [128][B] per-sequence row sums of dg / da_out (both tables or neither).
+ * d_u0 [B][h][L] (batch stride d_u0_bs) is accumulated into in place.  fst_wn_stack_bwd_ok: 1 when (n, h, L, nl) is served. */
+int fst_wn_stack_bwd_ok(int n, int h, int L, int nl);
+int fst_wn_stack_bwd(const float* const* ts, const void* const* img_b, const void* const* img_d, float* const* dg,
+                     const float* const* da_in, float* const* da_out, float* const* rs_b /* optional */,
+                     float* const* rs_d /* optional */, const float* d_out, float* d_u0, int64_t d_u0_bs, int nl, int B, int L,
+                     int n, int h, int64_t numel_a, void* stream);
+
 /* Weight gradients of the same layer (the gradients autograd derives for Simplified_NF_WaveGlow.py:107-116), time as the MFMA
  * reduction index, split-bf16 products, per-workgroup partial slabs added in a fixed order (deterministic, no atomics):
  *   fst_wn_wgrad_in   dw_in[m][c][τ] = Σ_{b,t} dg[b,m,t]·a[b,c,t+(τ−1)·dil]   ([2n][n][3]),   dw_cond[m][c] = Σ dg[b,m,t]·u0[b,c,t]  ([2n][h])

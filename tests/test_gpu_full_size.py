@@ -294,3 +294,80 @@ def test_time_as_k_weight_gradients_summed_over_operand_sets(n, h, Bq, L, dil, n
         assert_close(dw[:, :, 0], want, 1e-4, f"res_skip dW over sets (last={last})")
     with pytest.raises(ValueError):
         ops.wn_wgrad_in(dgd * 2, a * 2, u0 * 2, dw_in, dw_cond, n, h, dil)          # 4+ sets: the caller chunks
+
+
+def _wn_reference_f64(S, u0, flat, do):
+    """fp64 autograd reference of the WN stack (Simplified_NF_WaveGlow.py:101-123 on folded weights) on the device."""
+    nl, n, h = S.n_layers, S.n, S.h
+    u0 = u0.double().requires_grad_(True)
+    flat = flat.double().requires_grad_(True)
+    w = S.unflatten(flat)
+    start_w, start_b, cond_w, cond_b, end_w, end_b = w[:6]
+    in_w, in_b = w[6: 6 + nl], w[6 + nl: 6 + 2 * nl]
+    rs_w, rs_b = w[6 + 2 * nl: 6 + 3 * nl], w[6 + 3 * nl: 6 + 4 * nl]
+    a = F.conv1d(u0, start_w, start_b)
+    cond = F.conv1d(u0, cond_w, cond_b)
+    out = 0
+    for i in range(nl):
+        g = F.conv1d(a, in_w[i], in_b[i], dilation=2 ** i, padding=2 ** i) + cond[:, 2 * n * i: 2 * n * (i + 1)]
+        acts = torch.tanh(g[:, :n]) * torch.sigmoid(g[:, n:])
+        rs = F.conv1d(acts, rs_w[i], rs_b[i])
+        if i < nl - 1:
+            a = a + rs[:, :n]
+            out = out + rs[:, n:]
+        else:
+            out = out + rs
+    o = F.conv1d(out, end_w, end_b)
+    d_u0, d_flat = torch.autograd.grad(o, (u0, flat), do.double())
+    return o.detach(), d_u0, d_flat
+
+
+@bf3_only
+@pytest.mark.parametrize("n,h,Bq,L,nl", [(120, 25, 256, 512, 8),     # the metric configuration: one sequence per CU, every dilation up to 128
+                                         (120, 25, 3, 512, 8), (120, 25, 300, 256, 8),   # fewer / more sequences than CUs (persistent loop)
+                                         (120, 25, 2, 148, 8),        # GunPoint-like length: partial column blocks, dilation 128 > L/2
+                                         (16, 5, 5, 64, 3), (33, 31, 2, 96, 4), (127, 32, 2, 128, 1), (8, 3, 3, 32, 2)])
+def test_wn_stack_backward_in_one_launch(n, h, Bq, L, nl, monkeypatch):
+    """fst_wn_stack_bwd — every layer's backward of a WN stack as one persistent launch — against (a) the fp64 autograd
+    reference of the stack (input gradient, all weight and bias gradients) and (b) the layer-wise launches it replaces, both
+    with weight gradients (the full backward: dg / d_a of every layer kept) and without (GradNorm's partial passes: scratch
+    tensors rewritten layer after layer).  Reference: the backward autograd derives for Simplified_NF_WaveGlow.py:101-123."""
+    g = torch.Generator(device=DEV).manual_seed(n * 31 + L + nl)
+    S = ops.WNSpecs(h, n, nl)
+    assert ops.wn_stack_bwd_ok(n, h, L, nl)
+    ws = []
+    for j, sh in enumerate(S.shapes):
+        fan = sh[1] * sh[2] if len(sh) == 3 else 1
+        ws.append(_rnd(g, *sh, k=(1.0 / fan ** 0.5 if len(sh) == 3 else 0.1)))
+    flat = S.flatten(ws)
+    x = _rnd(g, Bq, 2 * h, L)
+    do = _rnd(g, Bq, 2 * h, L)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FST_WN_STACK", mode)
+        for partial in (False, True):
+            u0 = x[:, :h].detach().requires_grad_(True)                 # a channel-slice view, as the flow passes it
+            fl = flat.detach().clone().requires_grad_(True)
+            with ops.pack_cache():
+                o = ops.WNFn.apply(S, u0, fl)
+                if partial:
+                    with ops.partial_backward():
+                        (d_u0,) = torch.autograd.grad(o, (u0,), do)
+                    d_fl = None
+                else:
+                    d_u0, d_fl = torch.autograd.grad(o, (u0, fl), do)
+            runs[(mode, partial)] = (o.detach(), d_u0, d_fl)
+    o_ref, du_ref, dw_ref = _wn_reference_f64(S, x[:, :h], flat, do)
+    assert_close(runs[("1", False)][0], o_ref, 2e-5, "WN output")
+    for partial in (False, True):
+        assert_close(runs[("1", partial)][1], du_ref, 5e-5, f"stack kernel d_u0 (partial={partial}) vs fp64")
+        assert_close(runs[("1", partial)][1], runs[("0", partial)][1], 2e-5, f"stack kernel d_u0 (partial={partial}) vs layer-wise launches")
+    for i, (lo, hi) in enumerate(zip(S.offsets[:-1], S.offsets[1:])):
+        assert_close(runs[("1", False)][2][lo:hi], dw_ref[lo:hi], 1e-4, f"stack kernel weight gradient segment {i}")
+    # twice the same numbers (fixed-order row sums, no atomics)
+    monkeypatch.setenv("FST_WN_STACK", "1")
+    u0 = x[:, :h].detach().requires_grad_(True)
+    fl = flat.detach().clone().requires_grad_(True)
+    with ops.pack_cache():
+        d_u0, d_fl = torch.autograd.grad(ops.WNFn.apply(S, u0, fl), (u0, fl), do)
+    assert torch.equal(d_u0, runs[("1", False)][1]) and torch.equal(d_fl, runs[("1", False)][2])
