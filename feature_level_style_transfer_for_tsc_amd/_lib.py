@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
@@ -57,7 +57,7 @@ _SIGNATURES = {
     "fst_rmsprop_multi": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, c_float, c_void_p]),
     "fst_adam_multi": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_float, c_float, c_float, c_float, c_void_p]),
     "fst_wn_stack_bwd_ok": (c_int, [c_int, c_int, c_int, c_int]),
-    "fst_wn_stack_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_wn_stack_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_wgrad_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "fst_wn_wgrad_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "fst_wn_wgrad_in": (c_int, [_P, _P, _P, c_int, c_int64, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
@@ -86,7 +86,7 @@ _SIGNATURES = {
     "fst_wn_layer_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int64, c_void_p]),
     "fst_wn_bwd_image_bytes": (c_int64, [c_int, c_int]),
-    "fst_wn_pack_bwd": (c_int, [_P, c_int, c_int, _P, c_int64, c_void_p]),
+    "fst_wn_pack_bwd": (c_int, [_P, c_int, c_int, c_int, _P, c_int64, c_void_p]),
     "fst_wn_layer_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_dgrad_image_bytes": (c_int64, [c_int]),
     "fst_wn_pack_dgrad": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int64, c_void_p]),

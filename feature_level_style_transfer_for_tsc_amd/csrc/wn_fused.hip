@@ -700,6 +700,7 @@ struct WnPackBwdParams {
   const float* rs_w;   // [2n][n] (last: [n][n])
   int n, last, CH;
   uint4* img;
+  int acc_order;       // the d_a stages in the k-order in which a 32x32 accumulator tile delivers its rows as a B operand
 };
 
 __global__ __launch_bounds__(64) void wn_pack_bwd_kernel(WnPackBwdParams p) {
@@ -709,7 +710,10 @@ __global__ __launch_bounds__(64) void wn_pack_bwd_kernel(WnPackBwdParams p) {
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int ch = 16 * c + 8 * hh + j;
+    // acc_order (fst_wn_stack_bwd keeps d_a in its accumulators and multiplies straight out of them): element j of lane half
+    // hh multiplies row 16c + 8(j>>2) + 4hh + (j&3) — registers 8s..8s+7 of the tile of row block c>>1, s = c&1
+    const bool perm = p.acc_order && !p.last && src == 0;
+    const int ch = 16 * c + (perm ? 8 * (j >> 2) + 4 * hh + (j & 3) : 8 * hh + j);
     v[j] = (m < n && ch < n) ? p.rs_w[(long long)(src * n + ch) * n + m] : 0.f;
   }
   unsigned hi[4], lo[4];
@@ -726,12 +730,12 @@ extern "C" int64_t fst_wn_bwd_image_bytes(int n, int last) {
   return (int64_t)(last ? 1 : 2) * wn_ch(n) * WN_BW_A + 16;
 }
 
-extern "C" int fst_wn_pack_bwd(const float* rs_w, int n, int last, void* image, int64_t image_bytes, void* stream) {
+extern "C" int fst_wn_pack_bwd(const float* rs_w, int n, int last, int acc_order, void* image, int64_t image_bytes, void* stream) {
   FST_REQUIRE(rs_w && image && n > 0 && n <= 128, "fst_wn_pack_bwd: bad arguments (n=%d, needs n <= 128)", n);
   FST_REQUIRE(image_bytes == fst_wn_bwd_image_bytes(n, last), "fst_wn_pack_bwd: image is %lld bytes, expected %lld",
               (long long)image_bytes, (long long)fst_wn_bwd_image_bytes(n, last));
   FST_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, "fst_wn_pack_bwd: image must be 16-byte aligned");
-  WnPackBwdParams p = {rs_w, n, last ? 1 : 0, wn_ch(n), static_cast<uint4*>(image)};
+  WnPackBwdParams p = {rs_w, n, last ? 1 : 0, wn_ch(n), static_cast<uint4*>(image), acc_order ? 1 : 0};
   const int stages = (last ? 1 : 2) * p.CH;
   hipLaunchKernelGGL(wn_pack_bwd_kernel, dim3((unsigned)(stages * 4)), dim3(64), 0, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
@@ -1286,36 +1290,41 @@ __device__ __forceinline__ void ws_acc_store(const V& v, __amdgpu_buffer_rsrc_t 
 // The whole backward of a WN stack in ONE persistent launch (sequences of up to 512 samples)
 //
 // fst_wn_layer_bwd + fst_wn_layer_dgrad, per layer, are two launches whose every workgroup walks the same phases at the same
-// time — operand loads (HBM), the GEMM (matrix cores), stores (HBM) — so the chip alternates between an idle matrix pipe and an
-// idle memory system, and d_a / dg / d_u0 make a round trip through HBM at every launch boundary.  With L <= 512 a 512-sample
-// tile IS a whole sequence: the dilated taps never look outside the tile, so the chain
+// time — operand loads, the GEMM, stores — and d_a / dg / d_u0 make a round trip through the memory fabric at every launch
+// boundary: 660 MB per layer at B=256, L=512 (counters: profiles/r04_stack_*), which is what bounds them.  With L <= 512 a
+// 512-sample tile IS a whole sequence: the dilated taps never look outside the tile, so the chain
 //     dacts = W_rsᵀ·[d_a ; d_out]  →  dg = gate'(t, s)·dacts  →  d_a += W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg        (layer nl−1 … 0)
 // of one batch element depends on nothing another workgroup produces.  One workgroup (8 waves × 64 samples) therefore walks
-// all layers of its batch element: what it writes in one phase (dg, d_a, d_u0) it reads back in the next while the lines are
-// still in its L2 / the Infinity Cache, the launch boundaries (2 per layer) are gone, and — nothing synchronising the
-// workgroups with each other — the CUs drift apart, so one CU's load / store phases run under other CUs' GEMM phases.
-// In GradNorm's partial passes (no weight gradients) dg and the intermediate d_a live in small scratch buffers that are rewritten
-// layer after layer and never have to reach HBM; the full pass keeps every layer's dg and d_a (the weight-gradient operands).
+// all layers of its batch element and d_a NEVER LEAVES ITS ACCUMULATORS: phase B (the data gradient) accumulates into them,
+// phase A (res_skip / gate backward) multiplies straight out of them — an accumulator tile is, register for register, the B
+// operand of an MFMA that sums over its rows; the weight image holds the d_a stages in that k-order (fst_wn_pack_bwd,
+// acc_order) — and d_a is stored only where something outside reads it (layer 0: the start conv; every layer in the full
+// pass: the res_skip weight gradients).  That takes the three d_a passes (189 of the 660 MB) off the fabric, the launch
+// boundaries (2 per layer) are gone, and — nothing synchronising the workgroups with each other — the CUs drift apart, so one
+// CU's load / store phases run under other CUs' GEMM phases.  In GradNorm's partial passes (no weight gradients) dg lives in a
+// scratch tensor that is rewritten layer after layer.
 //
-// Phase A = the body of wn_layer_bwd_kernel on a 512-sample tile (8 waves × 2 column blocks; the d_out stages first: they do
-// not depend on the phase before).  Phase B = the body of wn_layer_dgrad_kernel.  Global stores of one phase are read by the
-// next through LDS-DMA / loads of the SAME workgroup: s_waitcnt vmcnt(0) by every wave + a workgroup barrier orders them (one CU,
-// one L1: workgroup-scope coherence needs no cache maintenance).
+// Phase A runs as TWO column passes (the wave's two 32-sample column blocks one after the other): d_a occupies 128 registers,
+// so the dacts accumulators get 64 (4 row blocks × 1 column block).  Per pass: the d_out stages (operand through the LDS-DMA
+// ring; they depend on nothing the previous phase stored, so the first two are issued under its last stores), then the d_a
+// stages (weights through the ring, the operand from the accumulators), then the gate on four tiles.  Phase B = the body of
+// wn_layer_dgrad_kernel.  Global stores of one phase (dg, d_u0) are read by the next through LDS-DMA / loads of the SAME
+// workgroup: s_waitcnt vmcnt(0) by every wave + a workgroup barrier orders them (one CU, one L1).
 // ------------------------------------------------------------------------------------------------
 #define WS_MAXL 10
 #define WS_TN 512
-#define WS_NB (WS_TN / 32)                         // 32-sample column blocks of a phase-A window row group
+#define WS_NB 8                                    // 32-sample column blocks of a phase-A window row group: one per wave and column pass
 #define WS_GS (WS_NB * 1024 + 128)
 #define WS_SLOT_A (WN_BW_A + 2 * WS_GS)
-#define WS_LDS_A (3 * WS_SLOT_A)
+#define WS_RES_A (8 * WN_BW_A)                     // resident weights of the d_a stages (up to 8 chunks: n <= 128)
+#define WS_LDS_A (WS_RES_A + 2 * WS_SLOT_A)        // ... + the ring of two d_out stages
 
 struct WnStackParams {
   const float* ts[WS_MAXL];      // saved gate halves [B][2n][L] per layer
-  const char* img_b[WS_MAXL];    // fst_wn_pack_bwd images
+  const char* img_b[WS_MAXL];    // fst_wn_pack_bwd images (acc_order = 1)
   const char* img_d[WS_MAXL];    // fst_wn_pack_dgrad images
   float* dg[WS_MAXL];            // [B][2n][L] per layer (partial passes: one scratch tensor for all)
-  const float* da_in[WS_MAXL];   // cotangent of the layer's residual output [B][n][L]; null on the last layer
-  float* da_out[WS_MAXL];        // cotangent of the layer's input [B][n][L] (= da_in of the layer below)
+  float* da_out[WS_MAXL];        // cotangent of the layer's input [B][n][L]: written when not null (layer 0: always)
   float* rs_b[WS_MAXL];          // optional [256][B]: per-sequence Σ_t dg[row]
   float* rs_d[WS_MAXL];          // optional [128][B]: per-sequence Σ_t da_out[row]
   const float* d_out;            // [B][n][L]
@@ -1338,59 +1347,65 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_n0 = wave_s * 64;
   const int L = p.L, n = p.n, CH = p.CH, CHK = p.CHK;
-  // the epilogues' transpose tiles and row-sum arrays sit above the first two phase-A ring slots: the next layer's first two
-  // stages stream into those while a phase-B epilogue is still using the tiles
-  float* const tile = reinterpret_cast<float*>(ldsb + 2 * WS_SLOT_A + wave_s * WN_TILE_BYTES);
-  float* const rsum = reinterpret_cast<float*>(ldsb + 2 * WS_SLOT_A + 8 * WN_TILE_BYTES);        // [8 waves][256]
+  // phase A's LDS: [the weights of the d_a stages, resident for both column passes: CH x 8 KiB][a ring of two d_out stages][the
+  // epilogues' transpose tiles and row-sum arrays] — stages of the next pass / the next layer stream into the first two while an
+  // epilogue is still using the tiles
+  char* const ring_a = ldsb + WS_RES_A;
+  float* const tile = reinterpret_cast<float*>(ldsb + WS_LDS_A + wave_s * WN_TILE_BYTES);
+  float* const rsum = reinterpret_cast<float*>(ldsb + WS_LDS_A + 8 * WN_TILE_BYTES);        // [8 waves][256]
   float* const rsum_w = rsum + wave_s * 256;
   const unsigned vlane = (unsigned)(4 * half * L + l31) * 4u;
   const WsLane wl0 = ws_lane(vlane, wave_n0, L, lane), wl1 = ws_lane(vlane, wave_n0 + 32, L, lane);
 
-  // one stage of phase A of layer i into ring slot `slot`; stage k of the loop = image stage kk: the d_out stages first (nothing
-  // of the previous phase feeds them, so the first two are issued under the previous layer's last stores)
-  auto issue_a = [&](int i, int b, int k, int slot) {
+  // d_out stage g of phase A of layer i (g < 2·CH: column pass g / CH, chunk g % CH) into ring slot g & 1: 8 KiB of weights + the
+  // pass's 8 column blocks of 16 channels = three 1-KiB pieces per wave
+  auto issue_a = [&](int i, int b, int g) {
     const bool last = i == p.nl - 1;
+    const int pass = g >= CH ? 1 : 0, c = g - pass * CH;
     const char* const img = p.img_b[i];
-    const int S3 = (last ? 1 : 2) * CH;
-    const char* const zero16 = img + (long long)S3 * WN_BW_A;
-    const int kk = last ? k : (k < CH ? CH + k : k - CH);
-    char* const sl = ldsb + slot * WS_SLOT_A;
-    const char* asrc = img + (long long)kk * WN_BW_A;
-    const bool from_da = !last && kk < CH;
-    const int c = from_da ? kk : kk - (last ? 0 : CH);
-    const float* xb = (from_da ? p.da_in[i] : p.d_out) + ((long long)b * n + 16 * c) * L;
+    const char* const zero16 = img + (long long)((last ? 1 : 2) * CH) * WN_BW_A;
+    char* const sl = ring_a + (g & 1) * WS_SLOT_A;
+    const char* asrc = img + (long long)(last ? c : CH + c) * WN_BW_A;      // image: [d_a stages][d_out stages] (top layer: d_out only)
+    __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + wave_s * 1024 + lane * 16), WN_LDS_VOID(sl + wave_s * 1024), 16, 0, 0);
+    const float* xb = p.d_out + ((long long)b * n + 16 * c) * L;
     const int c_count = min(16, n - 16 * c);
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {                          // 8 pieces of A + 2 x 16 of B = 40 = five per wave
-      const int idx = wave_s + 8 * j;
-      if (idx < 8) {
-        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + idx * 1024 + lane * 16), WN_LDS_VOID(sl + idx * 1024), 16, 0, 0);
-      } else {
-        const int bi = idx - 8;
-        const int gq = bi >> 4, m = bi & 15;
-        const int row = 8 * gq + (lane >> 3);
-        const int t = 32 * m + 4 * (lane & 7);
-        const bool ok = row < c_count && t < L;
-        const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
-        __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_BW_A + gq * WS_GS + m * 1024), 16, 0, 0);
-      }
+    for (int j = 0; j < 2; ++j) {                          // 2 row groups x 8 column blocks = 16 pieces = two per wave
+      const int bi = wave_s + 8 * j;
+      const int gq = bi >> 3, m = bi & 7;
+      const int row = 8 * gq + (lane >> 3);
+      const int t = 64 * m + 32 * pass + 4 * (lane & 7);
+      const bool ok = row < c_count && t < L;
+      const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
+      __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_BW_A + gq * WS_GS + m * 1024), 16, 0, 0);
     }
+  };
+  // the weights of layer i's d_a stages (image stages 0 .. CH-1): CH pieces per wave, read by both column passes
+  auto issue_res = [&](int i) {
+    if (i == p.nl - 1) return;                             // the top layer has no residual output: no d_a stages
+    const char* const img = p.img_b[i];
+    for (int c = 0; c < CH; ++c)
+      __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(img + (long long)c * WN_BW_A + wave_s * 1024 + lane * 16),
+                                       WN_LDS_VOID(ldsb + c * WN_BW_A + wave_s * 1024), 16, 0, 0);
   };
 
   WN_SUMS;
   WN_T(tw0);
-  int primed = 0;                                          // how many of the first two phase-A stages of the layer at hand are already in flight
+  bool primed = false;                                     // the resident weights and the first d_out stage of the layer at hand are already in flight
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+    // acc[0..3] = the cotangent of the residual stream (d_a), carried from layer to layer; acc[4] = the conditioning rows (d_u0)
+    f32x16 acc[5][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][cb][r] = 0.f;     // the top layer has no residual output
     for (int i = p.nl - 1; i >= 0; --i) {
       const bool last = i == p.nl - 1;
-      // accumulators of both phases: phase A multiplies into [0..3] (its dacts rows); as the gate consumes a tile, that tile's
-      // registers receive the d_a tile phase B starts from, so those loads fly under the rest of the gate epilogue
-      f32x16 acc[5][2];
-      const float* const da_b = last ? nullptr : p.da_in[i] + (long long)b * n * L;
-      const __amdgpu_buffer_rsrc_t da_r = ws_rsrc(da_b);
       // ============================================================ phase A: dg = gate'(t, s) · W_rsᵀ·[d_a ; d_out]
       {
-        const int S3 = (last ? 1 : 2) * CH;
+        const int G = 2 * CH;                                // d_out stages of both column passes
         // the tanh | sigmoid halves are two [n][L] matrices
         const __amdgpu_buffer_rsrc_t ts_t = ws_rsrc(p.ts[i] + (long long)b * (2 * n) * L);
         const __amdgpu_buffer_rsrc_t ts_s = ws_rsrc(p.ts[i] + ((long long)b * 2 + 1) * n * L);
@@ -1398,28 +1413,45 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
         const __amdgpu_buffer_rsrc_t dg_s = ws_rsrc(p.dg[i] + ((long long)b * 2 + 1) * n * L);
         float* const rs_out = p.rs_b[i];
         WN_T(ta0);
+        if (!primed) {
+          issue_res(i);
+          issue_a(i, b, 0);
+        }
+        primed = false;
+        int g = 0;
+        if (rs_out) {                                      // (the tiles / row sums live above the ring)
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][cb][r] = 0.f;
-        if (primed < 1) issue_a(i, b, 0, 0);
-        if (primed < 2 && S3 > 1) issue_a(i, b, 1, 1);
-        primed = 0;
-        int slot = 0;
+          for (int w = 0; w < 4; ++w) rsum[w * 512 + tid] = 0.f;
+        }
         WN_T(ta1);
         WN_ACC(0, ta0, ta1);                             // phase A: ring priming (issue)
-        for (int k = 0; k < S3; ++k) {
-          if (k + 1 < S3) wn_wait_vmcnt<5>(); else wn_wait_vmcnt<0>();
-          __builtin_amdgcn_s_barrier();
-          if (k + 2 < S3) issue_a(i, b, k + 2, slot >= 1 ? slot - 1 : 2);
-          const char* base = ldsb + slot * WS_SLOT_A;
-          wn_bf16x8 bh[2], bl[2];
+        auto run_pass = [&](auto pc) {
+          constexpr int cb = decltype(pc)::value;
+          const WsLane wl = cb ? wl1 : wl0;
+          const int tcol = wave_n0 + 32 * cb;
+          f32x16 da[4];                                    // dacts rows of this column block
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) {
-            const int colx = wave_n0 + 32 * cb + l31;
-            const char* bp = base + WN_BW_A + half * WS_GS + (colx >> 5) * 1024 + (colx & 31) * 4;
+          for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) da[mb][r] = 0.f;
+          auto multiply = [&](const char* base, const wn_bf16x8 bh, const wn_bf16x8 bl) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+              const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
+              const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+              da[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, da[mb], 0, 0, 0);
+              da[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, da[mb], 0, 0, 0);
+              da[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, da[mb], 0, 0, 0);
+            }
+          };
+          WN_T(tp0);
+          // ---- the d_out stages: operand from the ring (two slots: stage g + 1 in flight while stage g is multiplied)
+          for (int k = 0; k < CH; ++k, ++g) {
+            wn_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (g + 1 < G) issue_a(i, b, g + 1);
+            const char* base = ring_a + (g & 1) * WS_SLOT_A;
+            const char* bp = base + WN_BW_A + half * WS_GS + wave_s * 1024 + l31 * 4;
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
@@ -1430,69 +1462,64 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
               wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
               bh4[j] = hh; bl4[j] = ll;
             }
-            bh[cb] = __builtin_bit_cast(wn_bf16x8, bh4); bl[cb] = __builtin_bit_cast(wn_bf16x8, bl4);
+            multiply(base, __builtin_bit_cast(wn_bf16x8, bh4), __builtin_bit_cast(wn_bf16x8, bl4));
           }
+          // ---- the d_a stages: weights resident (they landed before the first d_out stage's barrier), the operand IS the
+          // accumulator tile (registers 8s..8s+7 of row block c>>1 are k-step c&1): no ring, no barrier
+          if (!last) {
+            auto da_stage = [&](auto cc) {
+              constexpr int c = decltype(cc)::value;
+              if (c < CH) {                                // wave-uniform
+                wn_u32x4 bh4, bl4;
 #pragma unroll
-          for (int mb = 0; mb < 4; ++mb) {
-            const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
-            const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+                for (int j = 0; j < 4; ++j) {
+                  unsigned hh, ll;
+                  wn_split_pair(acc[c >> 1][cb][8 * (c & 1) + 2 * j], acc[c >> 1][cb][8 * (c & 1) + 2 * j + 1], hh, ll);
+                  bh4[j] = hh; bl4[j] = ll;
+                }
+                multiply(ldsb + c * WN_BW_A, __builtin_bit_cast(wn_bf16x8, bh4), __builtin_bit_cast(wn_bf16x8, bl4));
+                __builtin_amdgcn_sched_barrier(0);        // stage by stage: hoisted fragment reads of later stages cost registers
+              }
+            };
+            da_stage(std::integral_constant<int, 0>{}); da_stage(std::integral_constant<int, 1>{});
+            da_stage(std::integral_constant<int, 2>{}); da_stage(std::integral_constant<int, 3>{});
+            da_stage(std::integral_constant<int, 4>{}); da_stage(std::integral_constant<int, 5>{});
+            da_stage(std::integral_constant<int, 6>{}); da_stage(std::integral_constant<int, 7>{});
+          }
+          WN_T(tp1);
+          WN_ACC(1, tp0, tp1);                           // phase A: GEMM stages of a pass
+          // ---- gate: four tiles (row blocks) of this column block
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-              acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[cb], acc[mb][cb], 0, 0, 0);
-              acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[cb], acc[mb][cb], 0, 0, 0);
-              acc[mb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[cb], acc[mb][cb], 0, 0, 0);
+          for (int blk = 0; blk < 4; ++blk) {
+            const int rows_valid = n - blk * 32;
+            f32x16 tv, sv;
+            ws_acc_load(tv, ts_t, wl, blk * 32, tcol, rows_valid, L);
+            ws_acc_load(sv, ts_s, wl, blk * 32, tcol, rows_valid, L);
+            float gt[16], gs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = da[blk][r], t = tv[r], s2 = sv[r];
+              gt[r] = d * s2 * (1.f - t * t);
+              gs[r] = d * t * s2 * (1.f - s2);
             }
-          }
-          slot = slot == 2 ? 0 : slot + 1;
-        }
-        WN_T(ta2);
-        WN_ACC(1, ta1, ta2);                             // phase A: GEMM loop
-        // gate, eight (row block, column block) tiles per wave, the gate halves of the next tile in flight while one is gated
-        f32x16 tq[2], sq[2];
-        ws_acc_load(tq[0], ts_t, wl0, 0, wave_n0, n, L);
-        ws_acc_load(sq[0], ts_s, wl0, 0, wave_n0, n, L);
-        if (rs_out) {
-          __syncthreads();                               // every wave is past its last fragment read: the ring becomes tiles
+            ws_acc_store(gt, dg_t, wl, blk * 32, tcol, rows_valid, L);
+            ws_acc_store(gs, dg_s, wl, blk * 32, tcol, rows_valid, L);
+            if (rs_out) {
 #pragma unroll
-          for (int w = 0; w < 4; ++w) rsum[w * 512 + tid] = 0.f;
-          __syncthreads();
-        }
-        // (written as eight calls of a generic lambda: the optimizer refused to unroll the loop form, and the tile arrays then
-        // lived in scratch memory)
-        auto gate_tile = [&](auto qc) {
-          constexpr int q = decltype(qc)::value;
-          constexpr int blk = q >> 1, cb = q & 1;
-          const int rows_valid = n - blk * 32, tcol = wave_n0 + 32 * cb;
-          __builtin_amdgcn_sched_barrier(0);              // (tile by tile: a scheduler that hoists the loads of later tiles runs out of registers)
-          if (q < 7) {
-            constexpr int nb = (q + 1) >> 1, nc = (q + 1) & 1;
-            ws_acc_load(tq[(q + 1) & 1], ts_t, nc ? wl1 : wl0, nb * 32, wave_n0 + 32 * nc, n - nb * 32, L);
-            ws_acc_load(sq[(q + 1) & 1], ts_s, nc ? wl1 : wl0, nb * 32, wave_n0 + 32 * nc, n - nb * 32, L);
-          }
-          float gt[16], gs[16];
+              for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gt[r];
+              wn_tile_row_sums(tile, rsum_w, blk * 32, rows_valid, L, tcol, lane);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[blk][cb][r], t = tq[q & 1][r], s = sq[q & 1][r];
-            gt[r] = d * s * (1.f - t * t);
-            gs[r] = d * t * s * (1.f - s);
+              for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gs[r];
+              wn_tile_row_sums(tile, rsum_w, n + blk * 32, rows_valid, L, tcol, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);            // tile by tile (a scheduler that hoists the loads of later tiles runs out of registers)
           }
-          // the tile's registers are free: phase B's starting value (the residual cotangent; zeros when there is none)
-          ws_acc_load(acc[blk][cb], da_r, cb ? wl1 : wl0, blk * 32, tcol, da_b ? rows_valid : 0, L);
-          ws_acc_store(gt, dg_t, cb ? wl1 : wl0, blk * 32, tcol, rows_valid, L);
-          ws_acc_store(gs, dg_s, cb ? wl1 : wl0, blk * 32, tcol, rows_valid, L);
-          if (rs_out) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gt[r];
-            wn_tile_row_sums(tile, rsum_w, blk * 32, rows_valid, L, tcol, lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gs[r];
-            wn_tile_row_sums(tile, rsum_w, n + blk * 32, rows_valid, L, tcol, lane);
-          }
+          WN_T(tp2);
+          WN_ACC(2, tp1, tp2);                           // phase A: gate epilogue of a pass
         };
-        gate_tile(std::integral_constant<int, 0>{}); gate_tile(std::integral_constant<int, 1>{});
-        gate_tile(std::integral_constant<int, 2>{}); gate_tile(std::integral_constant<int, 3>{});
-        gate_tile(std::integral_constant<int, 4>{}); gate_tile(std::integral_constant<int, 5>{});
-        gate_tile(std::integral_constant<int, 6>{}); gate_tile(std::integral_constant<int, 7>{});
+        if (rs_out) __syncthreads();                       // row-sum arrays zeroed
+        run_pass(std::integral_constant<int, 0>{});
+        run_pass(std::integral_constant<int, 1>{});
         if (rs_out) {
           __syncthreads();
           if (tid < 256) {
@@ -1503,19 +1530,19 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
           }
         }
         WN_T(ta3);
-        WN_ACC(2, ta2, ta3);                             // phase A: gate epilogue (loads, stores, row sums: issue + waits)
         wn_wait_vmcnt<0>();                                  // this wave's dg stores have reached L2 ...
         __syncthreads();                                     // ... and so have everyone's: phase B may fetch them; the ring is free
         WN_T(ta4);
         WN_ACC(3, ta3, ta4);                             // phase A -> B: store drain + barrier
       }
-      // ============================================================ phase B: d_a = d_a_in + W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg
+      // ============================================================ phase B: d_a += W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg
       {
         const int dil = p.dil[i], nblkw = p.nblkw[i], gsw = p.gsw[i], slotb = p.slot_d[i];
         const char* const img = p.img_d[i];
         const char* const zero16 = img + (long long)CHK * DG_A_BYTES;
         const float* const dgr = p.dg[i] + (long long)b * (2 * n) * L;
-        const __amdgpu_buffer_rsrc_t dan_r = ws_rsrc(p.da_out[i] + (long long)b * n * L);
+        float* const da_store = p.da_out[i];
+        const __amdgpu_buffer_rsrc_t dan_r = ws_rsrc(da_store ? da_store + (long long)b * n * L : nullptr);
         const __amdgpu_buffer_rsrc_t du_r = ws_rsrc(p.d_u0 + (long long)b * p.d_u0_bs);
         float* const rs_out = p.rs_d[i];
         const int NI = DG_A_BLOCKS * 2 + 2 * nblkw;
@@ -1541,14 +1568,14 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
           }
         };
         WN_T(tb0);
-        // the d_a tiles were requested as phase A's gate released their registers; the conditioning rows here
+        // the d_a tiles are where the previous layer left them; the conditioning rows come from memory
         ws_acc_load(acc[4][0], du_r, wl0, 0, wave_n0, p.h, L);
         ws_acc_load(acc[4][1], du_r, wl1, 0, wave_n0 + 32, p.h, L);
         asm volatile("" ::: "memory");
         issue(0, 0);                                         // two ring slots: one stage in flight while one is multiplied
         int slot = 0;
         WN_T(tb1);
-        WN_ACC(4, tb0, tb1);                             // phase B: accumulator loads + first stage (issue)
+        WN_ACC(4, tb0, tb1);                             // phase B: conditioning-row loads + first stage (issue)
         for (int c = 0; c < CHK; ++c) {
           wn_wait_vmcnt<0>();
           __builtin_amdgcn_s_barrier();
@@ -1592,17 +1619,14 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
         WN_T(tb2);
         WN_ACC(5, tb1, tb2);                             // phase B: GEMM loop
         __syncthreads();                                     // every wave is past its last fragment read: the ring is free
-        // the d_out stages of the next phase A (the layer below, or the top layer of this workgroup's next sequence) depend on
-        // nothing this phase stores: into ring slots 0 and 1 now, under the stores below
+        // the resident weights and the first d_out stage of the next phase A (the layer below, or the top layer of this workgroup's
+        // next sequence) depend on nothing this phase stores: issued now, under the stores below
         {
           const int ni = i > 0 ? i - 1 : p.nl - 1, nb = i > 0 ? b : b + (int)gridDim.x;
           if (nb < p.B) {
-            issue_a(ni, nb, 0, 0);
-            primed = 1;
-            if (CH > 1) {                                    // stage 1 is a d_out stage too (with one chunk per source it is the d_a stage)
-              issue_a(ni, nb, 1, 1);
-              primed = 2;
-            }
+            issue_res(ni);
+            issue_a(ni, nb, 0);
+            primed = true;
           }
         }
         if (rs_out) {
@@ -1613,8 +1637,11 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
         for (int k = 0; k < 5 * DG_NCB; ++k) {
           const int ib = k / DG_NCB, cb = k % DG_NCB, tcol = wave_n0 + 32 * cb;
           const int rows = ib < 4 ? n - ib * 32 : p.h;
-          if (ib < 4) ws_acc_store(acc[ib][cb], dan_r, cb ? wl1 : wl0, ib * 32, tcol, rows, L);
-          else ws_acc_store(acc[ib][cb], du_r, cb ? wl1 : wl0, 0, tcol, rows, L);
+          if (ib < 4) {
+            if (da_store) ws_acc_store(acc[ib][cb], dan_r, cb ? wl1 : wl0, ib * 32, tcol, rows, L);
+          } else {
+            ws_acc_store(acc[ib][cb], du_r, cb ? wl1 : wl0, 0, tcol, rows, L);
+          }
           if (rs_out && ib < 4) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[ib][cb][r];
@@ -1632,8 +1659,7 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
         }
         WN_T(tb3);
         WN_ACC(6, tb2, tb3);                             // phase B: epilogue stores (issue)
-        // d_a / d_u0 of this layer must be in L2 before the d_a stages / the starting values of the next layer fetch them: the
-        // wait below also retires the two primed stages (issued before the stores: vmcnt is in order)
+        // d_u0 of this layer must be in L2 before the next layer's phase B reads it back (the wait also retires the primed stages)
         wn_wait_vmcnt<0>();
         __syncthreads();
         WN_T(tb4);
@@ -1655,34 +1681,31 @@ extern "C" int fst_wn_stack_bwd_ok(int n, int h, int L, int nl) {
 }
 
 extern "C" int fst_wn_stack_bwd(const float* const* ts, const void* const* img_b, const void* const* img_d, float* const* dg,
-                                const float* const* da_in, float* const* da_out, float* const* rs_b, float* const* rs_d,
-                                const float* d_out, float* d_u0, int64_t d_u0_bs, int nl, int B, int L, int n, int h,
-                                int64_t numel_a, void* stream) {
-  FST_REQUIRE(ts && img_b && img_d && dg && da_in && da_out && d_out && d_u0, "fst_wn_stack_bwd: null table");
+                                float* const* da_out, float* const* rs_b, float* const* rs_d, const float* d_out, float* d_u0,
+                                int64_t d_u0_bs, int nl, int B, int L, int n, int h, int64_t numel_a, void* stream) {
+  FST_REQUIRE(ts && img_b && img_d && dg && da_out && d_out && d_u0, "fst_wn_stack_bwd: null table");
   FST_REQUIRE(fst_wn_stack_bwd_ok(n, h, L, nl), "fst_wn_stack_bwd: not served: n=%d h=%d L=%d nl=%d (needs n <= 128, h <= 32, "
               "L <= 512, L %% 4 == 0, nl <= %d)", n, h, L, nl, WS_MAXL);
   FST_REQUIRE(B > 0 && (long long)B * n * L == (long long)numel_a,
               "fst_wn_stack_bwd: B*n*L does not match the element count %lld of the [B][n][L] tensors", (long long)numel_a);
   FST_REQUIRE(d_u0_bs >= (int64_t)h * L && d_u0_bs % 4 == 0,
               "fst_wn_stack_bwd: d_u0 batch stride %lld (needs >= h*L = %lld and a multiple of 4)", (long long)d_u0_bs, (long long)h * L);
+  FST_REQUIRE((rs_b == nullptr) == (rs_d == nullptr), "fst_wn_stack_bwd: row sums of both kinds or of neither");
   auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   WnStackParams p;
-  size_t lds_bytes = WS_LDS_A;
+  size_t lds_bytes = WS_LDS_A + 8 * WN_TILE_BYTES + 8192;            // phase A: the ring, the transpose tiles, the row-sum arrays
   for (int i = 0; i < nl; ++i) {
-    const bool last = i == nl - 1;
-    FST_REQUIRE(ts[i] && img_b[i] && img_d[i] && dg[i] && da_out[i] && (last || da_in[i]), "fst_wn_stack_bwd: null operand of layer %d", i);
-    FST_REQUIRE(al16(ts[i]) && al16(img_b[i]) && al16(img_d[i]) && al16(dg[i]) && al16(da_in[i]) && al16(da_out[i]),
+    FST_REQUIRE(ts[i] && img_b[i] && img_d[i] && dg[i] && (i > 0 || da_out[i]), "fst_wn_stack_bwd: null operand of layer %d", i);
+    FST_REQUIRE(al16(ts[i]) && al16(img_b[i]) && al16(img_d[i]) && al16(dg[i]) && al16(da_out[i]),
                 "fst_wn_stack_bwd: operands of layer %d must be 16-byte aligned", i);
-    FST_REQUIRE((rs_b == nullptr) == (rs_d == nullptr), "fst_wn_stack_bwd: row sums of both kinds or of neither");
     p.ts[i] = ts[i]; p.img_b[i] = static_cast<const char*>(img_b[i]); p.img_d[i] = static_cast<const char*>(img_d[i]);
-    p.dg[i] = dg[i]; p.da_in[i] = last ? nullptr : da_in[i]; p.da_out[i] = da_out[i];
+    p.dg[i] = dg[i]; p.da_out[i] = da_out[i];
     p.rs_b[i] = rs_b ? rs_b[i] : nullptr; p.rs_d[i] = rs_d ? rs_d[i] : nullptr;
     p.dil[i] = 1 << i;
     wn_dgrad_geometry(p.dil[i], &p.nblkw[i], &p.gsw[i], &p.slot_d[i]);
     if ((size_t)2 * p.slot_d[i] > lds_bytes) lds_bytes = (size_t)2 * p.slot_d[i];
   }
   FST_REQUIRE(al16(d_out) && al16(d_u0), "fst_wn_stack_bwd: d_out / d_u0 must be 16-byte aligned");
-  if (lds_bytes < 2 * WS_SLOT_A + 8 * WN_TILE_BYTES + 8192) lds_bytes = 2 * WS_SLOT_A + 8 * WN_TILE_BYTES + 8192;   // tiles + row sums above two phase-A slots
   FST_REQUIRE(lds_bytes <= 160 * 1024, "fst_wn_stack_bwd: %zu bytes of LDS", lds_bytes);
   p.d_out = d_out; p.d_u0 = d_u0; p.d_u0_bs = d_u0_bs;
   p.nl = nl; p.B = B; p.L = L; p.n = n; p.h = h; p.CH = wn_ch(n); p.CHK = (2 * n + 15) / 16;

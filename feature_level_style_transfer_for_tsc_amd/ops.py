@@ -1135,18 +1135,19 @@ def wn_layer_fwd(a: Tensor, u0: Tensor, img: Tensor, ts: Tensor, acts: Optional[
         KERNEL_TIMER.end("wn_layer_fwd_kernel", t0, flops, 4.0 * B * L * rows)
 
 
-def wn_pack_bwd(rs_w: Tensor, n: int, last: bool) -> Tensor:
+def wn_pack_bwd(rs_w: Tensor, n: int, last: bool, acc_order: bool = False) -> Tensor:
+    """``acc_order``: the image of fst_wn_stack_bwd (the d_a stages in the k-order of an accumulator tile's rows)."""
     lib = _lib.load()
     key = None
     if _PACK_CACHE is not None:
-        key = ("wn_bwd", n, last, rs_w.data_ptr(), rs_w._version)
+        key = ("wn_bwd", n, last, acc_order, rs_w.data_ptr(), rs_w._version)
         hit = _PACK_CACHE.get(key)
         if hit is not None:
             return hit[0]
     nbytes = lib.fst_wn_bwd_image_bytes(n, int(last))
     img = torch.empty(nbytes // 4, device=rs_w.device, dtype=torch.float32)
     src = rs_w.contiguous()
-    check(lib.fst_wn_pack_bwd(ptr(src), n, int(last), ptr(img), nbytes, stream_ptr()), "fst_wn_pack_bwd")
+    check(lib.fst_wn_pack_bwd(ptr(src), n, int(last), int(acc_order), ptr(img), nbytes, stream_ptr()), "fst_wn_pack_bwd")
     if key is not None:
         _PACK_CACHE[key] = (img, rs_w, src)
     return img
@@ -1270,16 +1271,18 @@ def _ptr_table(ts: Sequence[Optional[Tensor]]):
 
 
 def wn_stack_bwd(ts_list: Sequence[Tensor], imgs_b: Sequence[Tensor], imgs_d: Sequence[Tensor], dgs: Sequence[Tensor],
-                 da_in: Sequence[Optional[Tensor]], da_out: Sequence[Tensor], d_out: Tensor, d_u0: Tensor, n: int, h: int,
+                 da_out: Sequence[Optional[Tensor]], d_out: Tensor, d_u0: Tensor, n: int, h: int,
                  part_b: Optional[Tensor] = None, part_d: Optional[Tensor] = None) -> None:
     """Layers nl-1 .. 0 of a WN stack's backward in one launch (csrc/wn_fused.hip, fst_wn_stack_bwd): per layer
-    dg = gate'(t, s)·W_rsᵀ·[da_in ; d_out],  da_out = da_in + W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg.  ``dgs`` / ``da_out`` entries may
-    alias scratch tensors when nothing reads them afterwards (GradNorm's partial passes).  ``part_b`` [nl, 256, B] / ``part_d``
-    [nl, 128, B]: per-sequence row sums of dg / da_out (the bias gradients), both or neither."""
+    dg = gate'(t, s)·W_rsᵀ·[d_a ; d_out],  d_a += W_inᵀ (*) dg,  d_u0 += W_condᵀ·dg, the residual cotangent d_a staying in the
+    accumulators from layer to layer.  ``imgs_b``: ``wn_pack_bwd(..., acc_order=True)``.  ``da_out[i]`` (the cotangent of layer i's
+    input) is written where a tensor is given — ``da_out[0]`` always; the rest are the res_skip weight gradients' operands.
+    ``dgs`` entries may alias one scratch tensor when nothing reads dg afterwards (GradNorm's partial passes).  ``part_b``
+    [nl, 256, B] / ``part_d`` [nl, 128, B]: per-sequence row sums of dg / da_out (the bias gradients), both or neither."""
     lib = _lib.load()
     nl = len(ts_list)
     B, _, L = d_out.shape
-    numel = _same_numel(d_out, *[t for t in da_out], *[t for t in da_in if t is not None])
+    numel = _same_numel(d_out, *[t for t in da_out if t is not None])
     for t in list(ts_list) + list(dgs):
         if t.numel() != 2 * numel or not t.is_contiguous():
             raise ValueError("wn_stack_bwd: ts / dg must be contiguous [B, 2n, L]")
@@ -1294,14 +1297,14 @@ def wn_stack_bwd(ts_list: Sequence[Tensor], imgs_b: Sequence[Tensor], imgs_d: Se
     t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
     rs_b = None if part_b is None else _ptr_table([part_b[i] for i in range(nl)])
     rs_d = None if part_d is None else _ptr_table([part_d[i] for i in range(nl)])
-    check(lib.fst_wn_stack_bwd(_ptr_table(ts_list), _ptr_table(imgs_b), _ptr_table(imgs_d), _ptr_table(dgs), _ptr_table(da_in),
-                               _ptr_table(da_out), rs_b, rs_d, ptr(d_out), ptr(d_u0), d_u0_bs, nl, B, L, n, h, numel, stream_ptr()),
+    check(lib.fst_wn_stack_bwd(_ptr_table(ts_list), _ptr_table(imgs_b), _ptr_table(imgs_d), _ptr_table(dgs), _ptr_table(da_out),
+                               rs_b, rs_d, ptr(d_out), ptr(d_u0), d_u0_bs, nl, B, L, n, h, numel, stream_ptr()),
           "fst_wn_stack_bwd")
     if t0 is not None:
-        # per layer: GEMM 3 (K = 2n, n on the last layer) + the data gradient; bytes: d_out, t,s read, d_u0 in/out; dg and d_a are
-        # counted as written once and read once (what the per-layer launches move through HBM)
+        # per layer: GEMM 3 (K = 2n, n on the top layer) + the data gradient.  Algorithmic bytes (every operand once): t,s and
+        # d_out read, dg written and read back, d_u0 in/out, plus every d_a tensor that is written
         flops = 2.0 * B * L * (n * (2 * n * nl - n) + nl * 2 * n * (3 * n + h))
-        rows = nl * (n + 2 * n + 2 * h + 2 * 2 * n + 2 * n)
+        rows = nl * (2 * n + n + 2 * 2 * n + 2 * h) + n * sum(t is not None for t in da_out)
         KERNEL_TIMER.end("wn_stack_bwd_kernel", t0, flops, 4.0 * B * L * rows)
 
 
@@ -1417,20 +1420,19 @@ def _wn_backward(S: WNSpecs, fused: bool, sv, do: Tensor, d_u0: Tensor, need_w: 
     if stack:
         # ---- every layer in ONE persistent launch.  The full pass keeps each layer's dg and d_a (operands of the weight
         # gradients); a partial pass (GradNorm: no weight gradients) rewrites one dg and two d_a scratch tensors layer after layer
-        imgs_b = [wn_pack_bwd(rs_w[i], n, i == nl - 1) for i in range(nl)]
+        imgs_b = [wn_pack_bwd(rs_w[i], n, i == nl - 1, acc_order=True) for i in range(nl)]
         imgs_d = [wn_pack_dgrad(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], n, h) for i in range(nl)]
         new = lambda c: torch.empty(B, c, L, device=dev, dtype=torch.float32)
         if need_w:
             dgs = [new(2 * n) for _ in range(nl)]
             da_out = [new(n) for _ in range(nl)]
         else:
-            dg1, pp = new(2 * n), (new(n), new(n))
-            dgs = [dg1] * nl
-            da_out = [pp[i & 1] for i in range(nl)]
+            dgs = [new(2 * n)] * nl
+            da_out = [new(n)] + [None] * (nl - 1)         # d_a stays in the kernel's accumulators; only layer 0's leaves
         da_in = [da_out[i + 1] if i + 1 < nl else None for i in range(nl)]
         part_b = torch.empty(nl, 256, B, device=dev, dtype=torch.float32) if need_w else None
         part_d = torch.empty(nl, 128, B, device=dev, dtype=torch.float32) if need_w else None
-        wn_stack_bwd(ts_list, imgs_b, imgs_d, dgs, da_in, da_out, d_out, d_u0, n, h, part_b, part_d)
+        wn_stack_bwd(ts_list, imgs_b, imgs_d, dgs, da_out, d_out, d_u0, n, h, part_b, part_d)
         if need_w:
             for i in range(nl):
                 last = i == nl - 1

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 9
+#define FST_ABI_VERSION 10
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -235,7 +235,10 @@ int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, int64_t u0_b
  * (the transposed 1x1 conv autograd derives for Simplified_NF_WaveGlow.py:116 and the gate backward of :44-54).
  * ts = the (t | s) tensor fst_wn_layer_fwd saved; dg [B][2n][L] feeds the in_layer data / weight gradients. */
 int64_t fst_wn_bwd_image_bytes(int n, int last);
-int fst_wn_pack_bwd(const float* rs_w, int n, int last, void* image, int64_t image_bytes, void* stream);
+int fst_wn_pack_bwd(const float* rs_w, int n, int last,
+                    int acc_order /* 0: the image fst_wn_layer_bwd reads; 1: the d_a stages in the k-order in which a 32x32 accumulator
+                                     tile delivers its rows as a B operand — the image fst_wn_stack_bwd reads (ABI v10) */,
+                    void* image, int64_t image_bytes, void* stream);
 int fst_wn_layer_bwd(const float* d_a_next /* NULL iff last */, const float* d_out, const float* ts, const void* image,
                      int64_t image_bytes, float* dg,
                      float* row_sums /* optional [256][B·⌈L/128⌉]: per-workgroup Σ_t dg[row]; the caller adds each row's
@@ -261,18 +264,20 @@ int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, 
 /* The whole backward of a WN stack — fst_wn_layer_bwd and fst_wn_layer_dgrad of every layer, top layer first — as ONE persistent
  * launch (the backward autograd derives for the loop of Simplified_NF_WaveGlow.py:104-121), for sequences of up to 512 samples:
  * a 512-sample tile is then a whole sequence, the dilated taps never leave it, and one workgroup walks all layers of its batch
- * element; what a phase writes (dg, d_a, d_u0) the next reads back from L2 / the Infinity Cache, and the CUs are not held in
- * step by launch boundaries.  All tables are HOST arrays of nl entries (layer 0 = dilation 1 first; layer i has dilation 2^i):
- *   ts[i] the saved gate halves; img_b[i] / img_d[i] the fst_wn_pack_bwd / fst_wn_pack_dgrad images; dg[i] [B][2n][L] written
- *   (entries may alias each other when nothing reads dg afterwards); da_in[i] the cotangent of layer i's residual output
- *   (ignored for i = nl-1) and da_out[i] the cotangent of its input, written — da_out[i] is da_in[i-1]; rs_b[i] / rs_d[i]
+ * element with the cotangent of the residual stream (d_a) kept in its accumulators from layer to layer; what a phase writes
+ * (dg, d_u0) the next reads back from L2 / the Infinity Cache, and the CUs are not held in step by launch boundaries.
+ * All tables are HOST arrays of nl entries (layer 0 = dilation 1 first; layer i has dilation 2^i):
+ *   ts[i] the saved gate halves; img_b[i] the fst_wn_pack_bwd image with acc_order = 1; img_d[i] the fst_wn_pack_dgrad image;
+ *   dg[i] [B][2n][L] written (entries may alias each other when nothing reads dg afterwards); da_out[i] [B][n][L] the cotangent
+ *   of layer i's input, written when not NULL (da_out[0], the start conv's cotangent, is required; the others are the d_a
+ *   operands of the res_skip weight gradients: da_out[i+1] is the residual cotangent entering layer i); rs_b[i] / rs_d[i]
  *   optional [256][B] / [128][B] per-sequence row sums of dg / da_out (both tables or neither).
  * d_u0 [B][h][L] (batch stride d_u0_bs) is accumulated into in place.  fst_wn_stack_bwd_ok: 1 when (n, h, L, nl) is served. */
 int fst_wn_stack_bwd_ok(int n, int h, int L, int nl);
 int fst_wn_stack_bwd(const float* const* ts, const void* const* img_b, const void* const* img_d, float* const* dg,
-                     const float* const* da_in, float* const* da_out, float* const* rs_b /* optional */,
-                     float* const* rs_d /* optional */, const float* d_out, float* d_u0, int64_t d_u0_bs, int nl, int B, int L,
-                     int n, int h, int64_t numel_a, void* stream);
+                     float* const* da_out, float* const* rs_b /* optional */, float* const* rs_d /* optional */,
+                     const float* d_out, float* d_u0, int64_t d_u0_bs, int nl, int B, int L, int n, int h, int64_t numel_a,
+                     void* stream);
 
 /* Weight gradients of the same layer (the gradients autograd derives for Simplified_NF_WaveGlow.py:107-116), time as the MFMA
  * reduction index, split-bf16 products, per-workgroup partial slabs added in a fixed order (deterministic, no atomics):
