@@ -1249,6 +1249,7 @@ __device__ __forceinline__ int ws_opaque(int x) {
   asm volatile("" : "+s"(x));
   return x;
 }
+template <int AUX = 0>
 __device__ __forceinline__ void ws_acc_load(f32x16& v, __amdgpu_buffer_rsrc_t rs, const WsLane w, int row0, int tcol, int rv, int L) {
   L = ws_opaque(L);
   rv = ws_opaque(rv);
@@ -1256,18 +1257,18 @@ __device__ __forceinline__ void ws_acc_load(f32x16& v, __amdgpu_buffer_rsrc_t rs
   if (rv >= 32) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+      v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, AUX));
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2);
       float x = 0.f;
-      if (row < rv) x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, 0));
+      if (row < rv) x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, AUX));
       v[r] = x;
     }
   }
 }
-template <class V>
+template <int AUX = 0, class V>
 __device__ __forceinline__ void ws_acc_store(const V& v, __amdgpu_buffer_rsrc_t rs, const WsLane w, int row0, int tcol, int rv, int L) {
   L = ws_opaque(L);
   rv = ws_opaque(rv);
@@ -1275,15 +1276,41 @@ __device__ __forceinline__ void ws_acc_store(const V& v, __amdgpu_buffer_rsrc_t 
   if (rv >= 32) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, AUX);
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2);
       if (row < rv)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, AUX);
     }
   }
+}
+
+// Row sums of an accumulator tile WITHOUT an LDS transpose (the persistent kernel's LDS holds a layer's weights): a lane holds
+// 16 rows x 1 column; a halving butterfly over the 32 lanes of a half — at distance 16 a lane keeps registers 0-7 (bit 4 clear)
+// or 8-15 and adds the partner's copy of the same registers, at distance 8 four of those eight, ... — leaves every lane with ONE
+// row's total after 8 + 4 + 2 + 1 exchanges, one more at distance 1 completes it: 16 exchanges per tile instead of 80.
+// Lane l31 (even) of half hh ends with row (j&3) + 8(j>>2) + 4hh, j = 8·bit4 + 4·bit3 + 2·bit2 + bit1 of l31; it adds the total
+// to ITS entry of the wave's row array (plain read-modify-write in program order: the same sum in every run).
+__device__ __forceinline__ void ws_row_sums(const float (&v)[16], float* rows_w, int row0, int rows_valid, bool col_ok, int lane) {
+  const int l31 = lane & 31, half = lane >> 5;
+  float a8[8], a4[4], a2[2];
+  const bool b4 = (l31 & 16) != 0, b3 = (l31 & 8) != 0, b2 = (l31 & 4) != 0, b1 = (l31 & 2) != 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float lo = col_ok ? v[j] : 0.f, hi = col_ok ? v[8 + j] : 0.f;
+    a8[j] = (b4 ? hi : lo) + __shfl_xor(b4 ? lo : hi, 16, 64);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a4[j] = (b3 ? a8[4 + j] : a8[j]) + __shfl_xor(b3 ? a8[j] : a8[4 + j], 8, 64);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) a2[j] = (b2 ? a4[2 + j] : a4[j]) + __shfl_xor(b2 ? a4[j] : a4[2 + j], 4, 64);
+  float a1 = (b1 ? a2[1] : a2[0]) + __shfl_xor(b1 ? a2[0] : a2[1], 2, 64);
+  a1 += __shfl_xor(a1, 1, 64);
+  const int j = (b4 ? 8 : 0) + (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
+  const int row = (j & 3) + 8 * (j >> 2) + 4 * half;
+  if ((l31 & 1) == 0 && row < rows_valid) rows_w[row0 + row] += a1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1312,12 +1339,14 @@ __device__ __forceinline__ void ws_acc_store(const V& v, __amdgpu_buffer_rsrc_t 
 // workgroup: s_waitcnt vmcnt(0) by every wave + a workgroup barrier orders them (one CU, one L1).
 // ------------------------------------------------------------------------------------------------
 #define WS_MAXL 10
+#ifndef WS_NT
+#define WS_NT 0     // cache policy of the streamed tensors (t,s, dg, d_out): 0 default, 2 non-temporal
+#endif
 #define WS_TN 512
 #define WS_NB 8                                    // 32-sample column blocks of a phase-A window row group: one per wave and column pass
 #define WS_GS (WS_NB * 1024 + 128)
 #define WS_SLOT_A (WN_BW_A + 2 * WS_GS)
-#define WS_RES_A (8 * WN_BW_A)                     // resident weights of the d_a stages (up to 8 chunks: n <= 128)
-#define WS_LDS_A (WS_RES_A + 2 * WS_SLOT_A)        // ... + the ring of two d_out stages
+#define WS_LDS_A (16 * WN_BW_A)                     // a layer's resident W_rsᵀ image: up to 16 stages (n <= 128) of 8 KiB
 
 struct WnStackParams {
   const float* ts[WS_MAXL];      // saved gate halves [B][2n][L] per layer
@@ -1347,51 +1376,28 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_n0 = wave_s * 64;
   const int L = p.L, n = p.n, CH = p.CH, CHK = p.CHK;
-  // phase A's LDS: [the weights of the d_a stages, resident for both column passes: CH x 8 KiB][a ring of two d_out stages][the
-  // epilogues' transpose tiles and row-sum arrays] — stages of the next pass / the next layer stream into the first two while an
-  // epilogue is still using the tiles
-  char* const ring_a = ldsb + WS_RES_A;
-  float* const tile = reinterpret_cast<float*>(ldsb + WS_LDS_A + wave_s * WN_TILE_BYTES);
-  float* const rsum = reinterpret_cast<float*>(ldsb + WS_LDS_A + 8 * WN_TILE_BYTES);        // [8 waves][256]
+  // phase A's LDS: [the layer's whole W_rsᵀ image, resident for both column passes: up to 16 x 8 KiB][the row-sum arrays] — the
+  // next layer's image streams in while a phase-B epilogue is still adding row sums
+  float* const rsum = reinterpret_cast<float*>(ldsb + WS_LDS_A);        // [8 waves][256]
   float* const rsum_w = rsum + wave_s * 256;
   const unsigned vlane = (unsigned)(4 * half * L + l31) * 4u;
   const WsLane wl0 = ws_lane(vlane, wave_n0, L, lane), wl1 = ws_lane(vlane, wave_n0 + 32, L, lane);
 
-  // d_out stage g of phase A of layer i (g < 2·CH: column pass g / CH, chunk g % CH) into ring slot g & 1: 8 KiB of weights + the
-  // pass's 8 column blocks of 16 channels = three 1-KiB pieces per wave
-  auto issue_a = [&](int i, int b, int g) {
-    const bool last = i == p.nl - 1;
-    const int pass = g >= CH ? 1 : 0, c = g - pass * CH;
-    const char* const img = p.img_b[i];
-    const char* const zero16 = img + (long long)((last ? 1 : 2) * CH) * WN_BW_A;
-    char* const sl = ring_a + (g & 1) * WS_SLOT_A;
-    const char* asrc = img + (long long)(last ? c : CH + c) * WN_BW_A;      // image: [d_a stages][d_out stages] (top layer: d_out only)
-    __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(asrc + wave_s * 1024 + lane * 16), WN_LDS_VOID(sl + wave_s * 1024), 16, 0, 0);
-    const float* xb = p.d_out + ((long long)b * n + 16 * c) * L;
-    const int c_count = min(16, n - 16 * c);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                          // 2 row groups x 8 column blocks = 16 pieces = two per wave
-      const int bi = wave_s + 8 * j;
-      const int gq = bi >> 3, m = bi & 7;
-      const int row = 8 * gq + (lane >> 3);
-      const int t = 64 * m + 32 * pass + 4 * (lane & 7);
-      const bool ok = row < c_count && t < L;
-      const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
-      __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + WN_BW_A + gq * WS_GS + m * 1024), 16, 0, 0);
-    }
-  };
-  // the weights of layer i's d_a stages (image stages 0 .. CH-1): CH pieces per wave, read by both column passes
+  // layer i's W_rsᵀ image ([d_a stages][d_out stages]; the top layer: d_out stages only): one 1-KiB piece per wave and stage
   auto issue_res = [&](int i) {
-    if (i == p.nl - 1) return;                             // the top layer has no residual output: no d_a stages
+    const int S3 = (i == p.nl - 1 ? 1 : 2) * CH;
     const char* const img = p.img_b[i];
-    for (int c = 0; c < CH; ++c)
+    for (int c = 0; c < S3; ++c)
       __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(img + (long long)c * WN_BW_A + wave_s * 1024 + lane * 16),
                                        WN_LDS_VOID(ldsb + c * WN_BW_A + wave_s * 1024), 16, 0, 0);
   };
+  // per-lane byte offset of a B-fragment element of a [channel][time] matrix read straight from memory: lane half hh reads
+  // channels 8hh + j of a 16-channel chunk at column l31 of its block
+  const unsigned vfrag = (unsigned)(8 * half * L + l31) * 4u;
 
   WN_SUMS;
   WN_T(tw0);
-  bool primed = false;                                     // the resident weights and the first d_out stage of the layer at hand are already in flight
+  bool primed = false;                                     // the weight image of the layer at hand is already in flight
   for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
     // acc[0..3] = the cotangent of the residual stream (d_a), carried from layer to layer; acc[4] = the conditioning rows (d_u0)
     f32x16 acc[5][2];
@@ -1405,26 +1411,25 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
       const bool last = i == p.nl - 1;
       // ============================================================ phase A: dg = gate'(t, s) · W_rsᵀ·[d_a ; d_out]
       {
-        const int G = 2 * CH;                                // d_out stages of both column passes
         // the tanh | sigmoid halves are two [n][L] matrices
         const __amdgpu_buffer_rsrc_t ts_t = ws_rsrc(p.ts[i] + (long long)b * (2 * n) * L);
         const __amdgpu_buffer_rsrc_t ts_s = ws_rsrc(p.ts[i] + ((long long)b * 2 + 1) * n * L);
         const __amdgpu_buffer_rsrc_t dg_t = ws_rsrc(p.dg[i] + (long long)b * (2 * n) * L);
         const __amdgpu_buffer_rsrc_t dg_s = ws_rsrc(p.dg[i] + ((long long)b * 2 + 1) * n * L);
+        const __amdgpu_buffer_rsrc_t dout_r = ws_rsrc(p.d_out + (long long)b * n * L);
         float* const rs_out = p.rs_b[i];
         WN_T(ta0);
-        if (!primed) {
-          issue_res(i);
-          issue_a(i, b, 0);
-        }
+        if (!primed) issue_res(i);
         primed = false;
-        int g = 0;
-        if (rs_out) {                                      // (the tiles / row sums live above the ring)
+        if (rs_out) {
 #pragma unroll
           for (int w = 0; w < 4; ++w) rsum[w * 512 + tid] = 0.f;
         }
+        wn_wait_vmcnt<0>();                                  // this wave's pieces of the image have landed ...
+        __syncthreads();                                     // ... and everyone's; the row-sum arrays are zeroed
         WN_T(ta1);
-        WN_ACC(0, ta0, ta1);                             // phase A: ring priming (issue)
+        WN_ACC(0, ta0, ta1);                             // phase A: waiting for the weight image
+        const char* const w_dout = ldsb + (long long)(last ? 0 : CH) * WN_BW_A;
         auto run_pass = [&](auto pc) {
           constexpr int cb = decltype(pc)::value;
           const WsLane wl = cb ? wl1 : wl0;
@@ -1445,16 +1450,27 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
             }
           };
           WN_T(tp0);
-          // ---- the d_out stages: operand from the ring (two slots: stage g + 1 in flight while stage g is multiplied)
-          for (int k = 0; k < CH; ++k, ++g) {
-            wn_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (g + 1 < G) issue_a(i, b, g + 1);
-            const char* base = ring_a + (g & 1) * WS_SLOT_A;
-            const char* bp = base + WN_BW_A + half * WS_GS + wave_s * 1024 + l31 * 4;
+          // ---- the d_out stages: the operand comes straight from memory in fragment layout (eight dword loads per stage: lane
+          // half hh reads channels 8hh + j at its column), the next stage's in flight while one is multiplied — no ring, no barrier
+          const unsigned vf = tcol + l31 < L ? vfrag : WS_OOB, vf_lo = half == 0 ? vf : WS_OOB;
+          auto load_dout = [&](float (&v)[8], int c) {
+            const int Lq = ws_opaque(L), nq = ws_opaque(n);
+            const int sbase = (16 * c * Lq + tcol) * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float x = 0.f;
+              if (16 * c + j < nq)
+                x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dout_r, 16 * c + 8 + j < nq ? vf : vf_lo, sbase + j * Lq * 4, WS_NT));
+              v[j] = x;
+            }
+          };
+          float vn[8];
+          load_dout(vn, 0);
+          for (int k = 0; k < CH; ++k) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(bp + j * 128);
+            for (int j = 0; j < 8; ++j) v[j] = vn[j];
+            if (k + 1 < CH) load_dout(vn, k + 1);
             wn_u32x4 bh4, bl4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1462,10 +1478,9 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
               wn_split_pair(v[2 * j], v[2 * j + 1], hh, ll);
               bh4[j] = hh; bl4[j] = ll;
             }
-            multiply(base, __builtin_bit_cast(wn_bf16x8, bh4), __builtin_bit_cast(wn_bf16x8, bl4));
+            multiply(w_dout + k * WN_BW_A, __builtin_bit_cast(wn_bf16x8, bh4), __builtin_bit_cast(wn_bf16x8, bl4));
           }
-          // ---- the d_a stages: weights resident (they landed before the first d_out stage's barrier), the operand IS the
-          // accumulator tile (registers 8s..8s+7 of row block c>>1 are k-step c&1): no ring, no barrier
+          // ---- the d_a stages: the operand IS the accumulator tile (registers 8s..8s+7 of row block c>>1 are k-step c&1)
           if (!last) {
             auto da_stage = [&](auto cc) {
               constexpr int c = decltype(cc)::value;
@@ -1493,8 +1508,8 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
           for (int blk = 0; blk < 4; ++blk) {
             const int rows_valid = n - blk * 32;
             f32x16 tv, sv;
-            ws_acc_load(tv, ts_t, wl, blk * 32, tcol, rows_valid, L);
-            ws_acc_load(sv, ts_s, wl, blk * 32, tcol, rows_valid, L);
+            ws_acc_load<WS_NT>(tv, ts_t, wl, blk * 32, tcol, rows_valid, L);
+            ws_acc_load<WS_NT>(sv, ts_s, wl, blk * 32, tcol, rows_valid, L);
             float gt[16], gs[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1502,22 +1517,17 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
               gt[r] = d * s2 * (1.f - t * t);
               gs[r] = d * t * s2 * (1.f - s2);
             }
-            ws_acc_store(gt, dg_t, wl, blk * 32, tcol, rows_valid, L);
-            ws_acc_store(gs, dg_s, wl, blk * 32, tcol, rows_valid, L);
+            ws_acc_store<WS_NT>(gt, dg_t, wl, blk * 32, tcol, rows_valid, L);
+            ws_acc_store<WS_NT>(gs, dg_s, wl, blk * 32, tcol, rows_valid, L);
             if (rs_out) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gt[r];
-              wn_tile_row_sums(tile, rsum_w, blk * 32, rows_valid, L, tcol, lane);
-#pragma unroll
-              for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = gs[r];
-              wn_tile_row_sums(tile, rsum_w, n + blk * 32, rows_valid, L, tcol, lane);
+              ws_row_sums(gt, rsum_w, blk * 32, rows_valid, tcol + l31 < L, lane);
+              ws_row_sums(gs, rsum_w, n + blk * 32, rows_valid, tcol + l31 < L, lane);
             }
             __builtin_amdgcn_sched_barrier(0);            // tile by tile (a scheduler that hoists the loads of later tiles runs out of registers)
           }
           WN_T(tp2);
           WN_ACC(2, tp1, tp2);                           // phase A: gate epilogue of a pass
         };
-        if (rs_out) __syncthreads();                       // row-sum arrays zeroed
         run_pass(std::integral_constant<int, 0>{});
         run_pass(std::integral_constant<int, 1>{});
         if (rs_out) {
@@ -1563,7 +1573,7 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
               const int t = w4 + 32 * m + 4 * (lane & 7);
               const bool ok = row < c_count && t >= 0 && t < L;
               const char* src = ok ? reinterpret_cast<const char*>(xb + ((long long)row * L + t)) : zero16;
-              __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + DG_A_BYTES + gq * gsw + m * 1024), 16, 0, 0);
+              __builtin_amdgcn_global_load_lds(WN_GLOBAL_PTR(src), WN_LDS_VOID(sl + DG_A_BYTES + gq * gsw + m * 1024), 16, 0, WS_NT);
             }
           }
         };
@@ -1619,13 +1629,12 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
         WN_T(tb2);
         WN_ACC(5, tb1, tb2);                             // phase B: GEMM loop
         __syncthreads();                                     // every wave is past its last fragment read: the ring is free
-        // the resident weights and the first d_out stage of the next phase A (the layer below, or the top layer of this workgroup's
-        // next sequence) depend on nothing this phase stores: issued now, under the stores below
+        // the weight image of the next phase A (the layer below, or the top layer of this workgroup's next sequence) depends on
+        // nothing this phase stores: it streams into LDS now, under the stores below
         {
           const int ni = i > 0 ? i - 1 : p.nl - 1, nb = i > 0 ? b : b + (int)gridDim.x;
           if (nb < p.B) {
             issue_res(ni);
-            issue_a(ni, nb, 0);
             primed = true;
           }
         }
@@ -1643,9 +1652,10 @@ __global__ __launch_bounds__(512, 2) void wn_stack_bwd_kernel(WnStackParams p_by
             ws_acc_store(acc[ib][cb], du_r, cb ? wl1 : wl0, 0, tcol, rows, L);
           }
           if (rs_out && ib < 4) {
+            float av[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31] = acc[ib][cb][r];
-            wn_tile_row_sums(tile, rsum + wave_s * 128, ib * 32, rows, L, tcol, lane);
+            for (int r = 0; r < 16; ++r) av[r] = acc[ib][cb][r];
+            ws_row_sums(av, rsum + wave_s * 128, ib * 32, rows, tcol + l31 < L, lane);
           }
         }
         if (rs_out) {
@@ -1693,7 +1703,7 @@ extern "C" int fst_wn_stack_bwd(const float* const* ts, const void* const* img_b
   FST_REQUIRE((rs_b == nullptr) == (rs_d == nullptr), "fst_wn_stack_bwd: row sums of both kinds or of neither");
   auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   WnStackParams p;
-  size_t lds_bytes = WS_LDS_A + 8 * WN_TILE_BYTES + 8192;            // phase A: the ring, the transpose tiles, the row-sum arrays
+  size_t lds_bytes = WS_LDS_A + 8192;                                // phase A: the weight image and the row-sum arrays
   for (int i = 0; i < nl; ++i) {
     FST_REQUIRE(ts[i] && img_b[i] && img_d[i] && dg[i] && (i > 0 || da_out[i]), "fst_wn_stack_bwd: null operand of layer %d", i);
     FST_REQUIRE(al16(ts[i]) && al16(img_b[i]) && al16(img_d[i]) && al16(dg[i]) && al16(da_out[i]),
