@@ -260,7 +260,7 @@ def north_star_extras(fst, ops, trainer, x_t, B: int, L: int):
 
 def kernel_peak(key: str) -> float:
     """Dense MFMA peak (algorithmic TFLOP/s) of the instruction a conv-engine kernel is built on."""
-    bf3 = "bf3" in key or key.startswith("wn_layer_") or (key.startswith("conv_wgrad_kernel") and key.rstrip(">").endswith("true"))
+    bf3 = "bf3" in key or key.startswith(("wn_layer_", "wn_stack_")) or (key.startswith("conv_wgrad_kernel") and key.rstrip(">").endswith("true"))
     return BF16X3_MFMA_PEAK_TFLOPS if bf3 else F32_MFMA_PEAK_TFLOPS
 
 
@@ -397,7 +397,7 @@ def main() -> None:
         conv_ms = sum(v["total_ms"] for v in ks.values()) / n_timer_steps
         traffic, traffic_src = None, None
         # PMC passes cannot run inside bench.py: the newest committed counter summary that covers this kernel
-        for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+        for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))

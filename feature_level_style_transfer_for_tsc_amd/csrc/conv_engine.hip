@@ -186,8 +186,8 @@ __device__ __forceinline__ void conv_epilogue_mode(const ConvGemmParams& p, f32x
 // wave still reads anything stored there).
 template <int MB, int NB>
 __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16 (&acc)[MB][NB], int g, int b, int t0,
-                                              int wave_n0, int half, int l31, bool add_bias, float* lds) {
-  float* tile = lds + p.epi_lds_off + (wave_n0 / (NB * 32)) * (32 * 36);
+                                              int wave_n0, int half, int l31, bool add_bias, float* lds, int tile_idx = -1) {
+  float* tile = lds + p.epi_lds_off + (tile_idx >= 0 ? tile_idx : wave_n0 / (NB * 32)) * (32 * 36);
   const bool add = p.res != nullptr || (p.flags & (FST_EPI_ACC1 | FST_EPI_ACC2));
   if (p.flags & FST_EPI_ATOMIC)
     conv_epilogue_mode<MB, NB, 2, false>(p, acc, g, b, t0, wave_n0, half, l31, add_bias, tile);
@@ -914,6 +914,121 @@ __global__ __launch_bounds__(256, 2) void conv_win_bf3_kernel(ConvGemmParams p, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same window kernel with the waves split over OUTPUT ROWS instead of time (32-row M-groups, resident windows):
+// wave w takes the M-groups g ≡ w (mod 4), paired small-with-large so the four waves carry similar tap counts, against ALL
+// eight 32-sample column blocks of the 256-sample tile.  In conv_win_bf3_kernel<1, 2> every wave streams the weight
+// fragments of every M-group for its own 64 samples: four copies of the stream per workgroup through the vector-memory
+// pipe — 68 of the layer-1 kernel's 216 us (cost removal: profiles/r04_win_cost_removal.txt).  Here a fragment pair is
+// loaded by exactly one wave and feeds 24 MFMAs instead of 6; the waves share nothing but the read-only windows, so
+// after the staging barrier there is no synchronisation at all.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_win_rows_kernel(ConvGemmParams p, const int32_t* __restrict__ plan) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NB = 8, TILE_N = 256;
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const PlanView pv = plan_view(plan);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x / p.tiles_per_seq;
+  const int t0 = (blockIdx.x - b * p.tiles_per_seq) * TILE_N;
+  const int L = p.L, dil = pv.dil, G = pv.n_mgroups, Q = pv.n_chunks;
+  const int slot_bytes = p.ldw * 64;
+  // the union window of every (M-group, chunk): one common origin
+  int lo_all = 1 << 30, hi_all = -1;
+  for (int g = 0; g < G; ++g)
+    for (int q = 0; q < Q; ++q) {
+      const int32_t* e = pv.mg + 4 * (g * Q + q);
+      if (e[1] > e[0]) { lo_all = min(lo_all, e[0]); hi_all = max(hi_all, e[1]); }
+    }
+  const int jlo = lo_all * dil, width = (hi_all - 1 - lo_all) * dil + TILE_N;
+  for (int q = 0; q < Q; ++q) {                          // stage chunk q: thread = (time j, channel quad cq)
+    const int32_t* c = pv.chunk + 4 * q;
+    const int src = c[0], c_begin = c[1], c_count = c[2];
+    const float* xb = p.x[src] + (long long)b * p.x_bs[src] + (long long)c_begin * L;
+    const int tbase = t0 - pv.pad_left + jlo;
+    char* const hi_img = ldsb + q * slot_bytes;
+    char* const lo_img = hi_img + p.ldw * 32;
+    const int cq = tid & 3;
+    for (int j = tid >> 2; j < width; j += 64) {
+      const int t = tbase + j;
+      const bool t_ok = t >= 0 && t < L;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int cc = 4 * cq + k;
+        v[k] = (t_ok && cc < c_count) ? xb[(long long)cc * L + t] : 0.f;
+      }
+      unsigned h0, h1, l0, l1;
+      split_bf16_pair(v[0], v[1], h0, l0);
+      split_bf16_pair(v[2], v[3], h1, l1);
+      *reinterpret_cast<uint2*>(hi_img + j * 32 + cq * 8) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(lo_img + j * 32 + cq * 8) = make_uint2(l0, l1);
+    }
+  }
+  __syncthreads();
+  // M-groups of this wave: position i of its list is group 4i + w on even i, 4i + 3 - w on odd i (the tap count grows with
+  // the group index: alternating the direction pairs a wave's small groups with large ones)
+  for (int i = 0; 4 * i < G; ++i) {
+    const int g = 4 * i + ((i & 1) ? 3 - wave : wave);
+    if (g >= G) continue;
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+    for (int q = 0; q < Q; ++q) {
+      const int32_t* e = pv.mg + 4 * (g * Q + q);
+      const int lo = e[0], nk = e[1] - e[0];
+      if (nk <= 0) continue;
+      const uint4* ap = reinterpret_cast<const uint4*>(p.a) + (long long)e[3] * 128 + lane;
+      constexpr int RING = 4;
+      uint4 rh[RING], rl[RING];
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        const int kk = j < nk ? j : nk - 1;
+        rh[j] = ap[kk * 128];
+        rl[j] = ap[kk * 128 + 64];
+      }
+      const char* hi_img = ldsb + q * slot_bytes + (l31 - jlo) * 32 + half * 16;
+      const char* lo_img = hi_img + p.ldw * 32;
+      int tap = lo;
+      auto kstep = [&](const uint4 ah, const uint4 al) {
+        const int roff = tap * dil * 32;
+        const bf16x8 a_h = __builtin_bit_cast(bf16x8, ah), a_l = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hi_img + roff + nb * 1024);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(lo_img + roff + nb * 1024);
+          acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, bh, acc[0][nb], 0, 0, 0);
+          acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bl, acc[0][nb], 0, 0, 0);
+          acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h, bh, acc[0][nb], 0, 0, 0);
+        }
+        ++tap;
+      };
+      int kb = 0;
+      for (; kb + RING <= nk; kb += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+          const uint4 ah = rh[j], al = rl[j];
+          const int kn = kb + j + RING < nk ? kb + j + RING : nk - 1;
+          rh[j] = ap[kn * 128];
+          rl[j] = ap[kn * 128 + 64];
+          kstep(ah, al);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RING; ++j)
+        if (kb + j < nk) kstep(rh[j], rl[j]);
+    }
+    // plain stores only (the launcher sends residual / accumulate / atomic epilogues to conv_win_bf3_kernel): the other modes'
+    // operand arrays for eight column blocks would cost this kernel its registers
+    float* tile = lds + p.epi_lds_off + wave * (32 * 36);
+    if (p.epi_vec) conv_epilogue_mode<1, NB, 0, true>(p, acc, g, b, t0, 0, half, l31, p.bias != nullptr, tile);
+    else conv_epilogue_mode<1, NB, 0, false>(p, acc, g, b, t0, 0, half, l31, p.bias != nullptr, tile);
+  }
+}
+
 static bool plan_is_pipeable(const PlanView& pv) {
   for (int q = 0; q < pv.n_chunks; ++q) {
     if (((pv.chunk[4 * q + 2] + 1) & ~1) > PIPE_C) return false;
@@ -1156,6 +1271,12 @@ extern "C" int fst_conv_gemm(const float* x0, int64_t x0_bs, const float* x1, in
     lds_bytes = (size_t)(resident ? pv.n_chunks : 1) * p.ldw * 64;
     p.epi_lds_off = (int)((lds_bytes / sizeof(float) + 3) / 4 * 4);
     lds_bytes = (size_t)p.epi_lds_off * sizeof(float) + epi_bytes;       // the epilogue's transpose tiles (vec or not)
+    // 32-row M-groups on 256-sample tiles with resident windows: the waves split over the M-groups instead of over time
+    // (conv_win_rows_kernel: a weight fragment is fetched by one wave, not by all four)
+    static const bool rows_off = getenv("FST_WIN_ROWS") && atoi(getenv("FST_WIN_ROWS")) == 0;     // diagnostics
+    if (resident && pv.MB == 1 && nb_cfg == 2 && pv.n_mgroups >= 4 && res == nullptr &&
+        !(flags & (FST_EPI_ATOMIC | FST_EPI_ACC1 | FST_EPI_ACC2)) && !rows_off)
+      fn = conv_win_rows_kernel;
   } else {
     p.epi_lds_off = (int)((lds_bytes / sizeof(float) + 3) / 4 * 4);   // after the staged window (reused across M-groups)
     if (p.epi_vec) lds_bytes = (size_t)p.epi_lds_off * sizeof(float) + epi_bytes;

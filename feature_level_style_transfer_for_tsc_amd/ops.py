@@ -371,6 +371,9 @@ class ConvSpec:
         if windowed_c >= 8 and MATH == "bf16x3":
             windowed_c, mb = min(windowed_c, PIPE_C), min(mb, 2)               # bf16 window kernel: 16-channel slots, MB <= 2
         best = 1
+        forced = int(os.environ.get("FST_WIN_NB", "0")) if windowed_c else 0           # diagnostics: force the window kernel's tile width
+        if forced in (1, 2, 4) and mb * forced <= 8 and forced <= max(1, tiles128):
+            return forced
         for nb in ((4, 2, 1) if windowed_c else (2, 1)):
             if mb * nb > 8 or nb > max(1, tiles128):
                 continue

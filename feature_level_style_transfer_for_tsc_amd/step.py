@@ -313,6 +313,10 @@ class JointTrainer:
     # ------------------------------------------------------------------ forward (train_and_test.py:547-603)
     def forward_losses(self, x_t, y_t, x_s, y_s, t_samples=(None, None), noise_ratios=None):
         m = self.m
+        # log|det W| of the flows' 1x1 weights: three single-workgroup launches that depend on the weights only — on the side stream,
+        # beside the feature extractors, instead of in the chain of the first flow pass
+        self._side.wait_stream(torch.cuda.current_stream())
+        m["nf"].prefetch_logdets(self._side)
         feat_t = m["fe_t"](x_t)
         feat_s = m["dimunif"](m["fe_s"](x_s))
         # The two CPC losses are ~3 k tiny launches (MIOpen's GRU runs step by step) that would leave the chip idle in
