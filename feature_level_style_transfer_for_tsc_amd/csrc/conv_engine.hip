@@ -1098,15 +1098,13 @@ static conv_gemm_fn pick_conv_win_bf3(int MB, int NB) {
     switch (MB) {
       case 1: return conv_win_bf3_kernel<1, 2>;
       case 2: return conv_win_bf3_kernel<2, 2>;
-      case 4: return conv_win_bf3_kernel<4, 2>;
     }
   } else if (NB == 4) {
     switch (MB) {
       case 1: return conv_win_bf3_kernel<1, 4>;
-      case 2: return conv_win_bf3_kernel<2, 4>;
     }
   }
-  return nullptr;
+  return nullptr;                                      // <4, 2> and <2, 4> (8 accumulator tiles + the fragment ring) spilled: not built; the host side never asks for them
 }
 
 static conv_gemm_fn pick_conv_gemm_bf3(int MB, int NB) {

@@ -368,14 +368,15 @@ class ConvSpec:
         many taps; channels are chunked to fit the LDS budget by ``_chunking``); otherwise the pipelined kernel,
         which has NB ∈ {1, 2}."""
         tiles128 = (L + 127) // 128
-        if windowed_c >= 8 and MATH == "bf16x3":
+        win_bf3 = windowed_c >= 8 and MATH == "bf16x3"
+        if win_bf3:
             windowed_c, mb = min(windowed_c, PIPE_C), min(mb, 2)               # bf16 window kernel: 16-channel slots, MB <= 2
         best = 1
         forced = int(os.environ.get("FST_WIN_NB", "0")) if windowed_c else 0           # diagnostics: force the window kernel's tile width
         if forced in (1, 2, 4) and mb * forced <= 8 and forced <= max(1, tiles128):
             return forced
         for nb in ((4, 2, 1) if windowed_c else (2, 1)):
-            if mb * nb > 8 or nb > max(1, tiles128):
+            if mb * nb > (4 if win_bf3 else 8) or nb > max(1, tiles128):       # bf16 window kernel: 8 tiles per wave spill (not built)
                 continue
             if windowed_c and windowed_c <= 64 and ((windowed_c + 1) & ~1) * (128 * nb + halo) * 4 > LDS_BUDGET:
                 continue
