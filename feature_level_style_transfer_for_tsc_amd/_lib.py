@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
@@ -99,8 +99,8 @@ _SIGNATURES = {
     "fst_lstm2_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int64, c_void_p]),
     "fst_axpy": (c_int, [_P, _P, c_float, c_int64, c_void_p]),
     "fst_add_slices": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, c_void_p]),
-    "fst_cpc_workspace_floats": (c_int64, [c_int, c_int, c_int]),
-    "fst_cpc_nce_slots": (c_int64, [c_int, c_int, c_int]),
+    "fst_cpc_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
+    "fst_cpc_nce_slots": (c_int64, [c_int, c_int, c_int, c_int]),
     "fst_cpc_nce_fwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_void_p]),
     "fst_cpc_nce_bwd": (c_int, [_P, c_int64, c_int64, c_int64, _I32P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                                 c_void_p]),

@@ -17,6 +17,7 @@
 // workspace that cpc_combine_kernel merges (online-softmax combine: lse = M + log Σ_p s_p·e^{m_p − M}), the backward —
 // lse known — is independent per panel: dpred rows of the panel written, denc accumulated over panels with fp32 atomics.
 #include "fst_common.h"
+#include <string.h>
 
 #define CPC_ROWS 16
 
@@ -159,6 +160,149 @@ __global__ __launch_bounds__(256) void cpc_fwd_kernel(CpcParams p) {
     // one slot per workgroup, summed by the caller in slot order: the loss is the same number in every run (a float atomic
     // per workgroup added them in arrival order)
     if (lane == 0) p.nce_sum[blockIdx.x * gridDim.y + blockIdx.y] = local;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward, one panel (Bc <= 256), C <= 64: the cross-Gram on the bf16 matrix cores with split operands
+// (hi·hi + hi·lo + lo·hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation: ≈5e-6 of the logit scale), K = C padded to 64.
+//
+// cpc_fwd_kernel reads enc_i[b][c] = feat[b][c][t0 + i] in place: for a fixed step every element sits in a different 128-byte
+// line, so a workgroup pulls 12.8 k lines for 51 KB of operand and the launch moves 130 MB for 39 MB of operands; and its
+// exact-f32 MFMA (25 k-steps of 64 cycles per tile) runs at 12 % of even the f32 peak.  Here
+//   cpc_enc_gather_kernel  transposes the T steps the loss reads into enc_t [T][B][C] through LDS — whole lines in, whole
+//                          lines out (13 + 13 MB);
+//   cpc_gram_bf3_kernel    one workgroup of 8 waves per step: pred_i and enc_i are staged ONCE as bf16 hi / lo images
+//                          [256 rows][64 channels] (144-byte rows: a 16-lane group's ds_read_b128 covers all 64 banks), wave w
+//                          keeps the B fragments of column tile w in registers for all eight row blocks (4 k-steps x 3 MFMAs
+//                          per tile), the log-softmax runs on the accumulators as in cpc_fwd_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 cg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float cg_f32x2 __attribute__((ext_vector_type(2)));
+#define CG_ROWB 144                                  // bytes per image row: 64 bf16 + 16 B so that rows start 36 banks apart
+#define CG_IMG (256 * CG_ROWB)
+
+__device__ __forceinline__ void cg_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  const cg_f32x2 v = {a, b};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, cg_bf16x2));
+  const cg_f32x2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, cg_bf16x2));
+}
+
+// enc_t[i][r] = enc[i·s_i + (b, c) strides], r = b·C + c: 64 rows x 32 steps per workgroup through an LDS tile
+__global__ __launch_bounds__(256) void cpc_enc_gather_kernel(CpcParams p, float* __restrict__ enc_t) {
+  __shared__ float tile[32][65];
+  if (p.t0_dev) p.enc += (long long)p.t0_dev[0] * p.s_i;
+  const int R = p.B * p.C, r0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
+  for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+    const int rr = idx >> 5, st = idx & 31;          // 32 consecutive lanes = 32 consecutive steps of one (b, c) row
+    const int r = r0 + rr, i = i0 + st;
+    float v = 0.f;
+    if (r < R && i < p.T) {
+      const int b = r / p.C, c = r - b * p.C;
+      v = p.enc[(long long)i * p.s_i + (long long)b * p.s_b + (long long)c * p.s_c];
+    }
+    tile[st][rr] = v;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+    const int st = idx >> 6, rr = idx & 63;          // 64 consecutive lanes = 64 consecutive (b, c) rows of one step
+    const int r = r0 + rr, i = i0 + st;
+    if (r < R && i < p.T) enc_t[(long long)i * R + r] = tile[st][rr];
+  }
+}
+
+__global__ __launch_bounds__(512) void cpc_gram_bf3_kernel(CpcParams p, const float* __restrict__ enc_t) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  char* const ph = ldsb, * const pl = ph + CG_IMG, * const eh = pl + CG_IMG, * const el = eh + CG_IMG;
+  float* const red = reinterpret_cast<float*>(el + CG_IMG);      // [3][8 waves][32 rows]: max, Σexp, diagonal
+  const int i = blockIdx.x, B = p.B, Bc = p.Bc, C = p.C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  // stage both operands: an item = 4 channels of one row -> 8 bytes of the hi image and of the lo image
+  auto stage = [&](const float* src, int rows, char* hi_img, char* lo_img) {
+    for (int idx = tid; idx < 256 * 16; idx += 512) {
+      const int row = idx >> 4, g4 = idx & 15;
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = 4 * g4 + k;
+        v[k] = (row < rows && c < C) ? src[(long long)row * C + c] : 0.f;
+      }
+      unsigned h0, h1, l0, l1;
+      cg_split_pair(v[0], v[1], h0, l0);
+      cg_split_pair(v[2], v[3], h1, l1);
+      *reinterpret_cast<uint2*>(hi_img + row * CG_ROWB + g4 * 8) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(lo_img + row * CG_ROWB + g4 * 8) = make_uint2(l0, l1);
+    }
+  };
+  stage(p.pred + (long long)i * Bc * C, Bc, ph, pl);
+  stage(enc_t + (long long)i * B * C, B, eh, el);
+  __syncthreads();
+  // The tile is computed TRANSPOSED — rows = predictions j (this wave's 32: its A fragments stay in registers), columns = the
+  // block's 32 encodings b — so the softmax of sample b runs over a lane's own 16 registers, one exchange between the lane
+  // halves and a combine over the eight waves through LDS (with samples on the rows a row's maximum is a 5-step butterfly per
+  // register: 240 dependent cross-lane exchanges per row block, which is what bounded the f32 kernel).
+  cg_bf16x8 ah[4], al[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    ah[ks] = *reinterpret_cast<const cg_bf16x8*>(ph + (wave * 32 + l31) * CG_ROWB + ks * 32 + half * 16);
+    al[ks] = *reinterpret_cast<const cg_bf16x8*>(pl + (wave * 32 + l31) * CG_ROWB + ks * 32 + half * 16);
+  }
+  float local = 0.f;
+  for (int r0 = 0; r0 < B; r0 += 32) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const cg_bf16x8 bh = *reinterpret_cast<const cg_bf16x8*>(eh + (r0 + l31) * CG_ROWB + ks * 32 + half * 16);
+      const cg_bf16x8 bl = *reinterpret_cast<const cg_bf16x8*>(el + (r0 + l31) * CG_ROWB + ks * 32 + half * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
+    }
+    // register r of a lane: prediction j = wave·32 + (r&3) + 8(r>>2) + 4·half, encoding b = r0 + l31
+    const int jb = wave * 32 + 4 * half;
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = jb + (r & 3) + 8 * (r >> 2);
+      if (j < Bc) m = fmaxf(m, acc[r]);
+      if (j == r0 + l31 + p.col_off) red[512 + l31] = acc[r];        // the positive of sample b: exactly one lane of one wave
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    if (half == 0) red[wave * 32 + l31] = m;
+    __syncthreads();
+    float M = red[l31];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) M = fmaxf(M, red[w * 32 + l31]);
+    float se = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = jb + (r & 3) + 8 * (r >> 2);
+      if (j < Bc) se += __expf(acc[r] - M);
+    }
+    se += __shfl_xor(se, 32, 64);
+    if (half == 0) red[256 + wave * 32 + l31] = se;
+    __syncthreads();
+    if (wave == 0 && half == 0) {
+      const int b = r0 + l31;
+      float s8 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s8 += red[256 + w * 32 + l31];
+      if (b < B) {
+        const float lse = M + logf(s8);
+        p.lse[(long long)i * B + b] = lse;
+        local += red[512 + l31] - lse;
+      }
+    }
+    __syncthreads();                                   // the statistics arrays are rewritten by the next row block
+  }
+  if (wave == 0) {
+    local = wave_sum_all(local);                       // (lanes 32-63 hold zeros)
+    if (lane == 0) p.nce_sum[i] = local;               // one slot per workgroup (= step), summed by the caller in slot order
   }
 }
 
@@ -338,9 +482,17 @@ static int cpc_check(const CpcParams& p, size_t lds_bytes, const char* who) {
   return 0;
 }
 
-extern "C" int64_t fst_cpc_workspace_floats(int T, int B, int Bc) {
+// the split-bf16 single-panel forward (cpc_enc_gather_kernel + cpc_gram_bf3_kernel) serves these shapes
+static inline bool cpc_gram_bf3_ok(int T, int B, int C, int Bc) {
+  static const bool off = getenv("FST_CPC_GRAM") && atoi(getenv("FST_CPC_GRAM")) == 0;     // diagnostics / FST_MATH=f32: the exact-f32 kernel
+  static const bool f32 = getenv("FST_MATH") && !strcmp(getenv("FST_MATH"), "f32");
+  return !off && !f32 && T > 0 && B > 0 && Bc <= CPC_PANEL && B <= 256 && C > 0 && C <= 64;
+}
+
+extern "C" int64_t fst_cpc_workspace_floats(int T, int B, int C, int Bc) {
   const int np = (Bc + CPC_PANEL - 1) / CPC_PANEL;
-  return np > 1 ? (int64_t)T * B * np * 3 : 0;
+  if (np > 1) return (int64_t)T * B * np * 3;          // per-panel softmax statistics
+  return cpc_gram_bf3_ok(T, B, C, Bc) ? (int64_t)T * B * C : 0;   // enc_t [T][B][C]
 }
 
 // launch geometry of the forward, shared by fst_cpc_nce_slots: pred_i is staged once per workgroup; ~512 workgroups: the row blocks
@@ -356,9 +508,10 @@ static inline long long cpc_combine_blocks(int T, int B) {
   return blocks > 1024 ? 1024 : blocks;
 }
 
-extern "C" int64_t fst_cpc_nce_slots(int T, int B, int Bc) {
+extern "C" int64_t fst_cpc_nce_slots(int T, int B, int C, int Bc) {
   if (T <= 0 || B <= 0 || Bc <= 0) return -1;
   const int np = (Bc + CPC_PANEL - 1) / CPC_PANEL;
+  if (np == 1 && cpc_gram_bf3_ok(T, B, C, Bc)) return T;
   return np > 1 ? 4 * cpc_combine_blocks(T, B) : (int64_t)T * cpc_fwd_ysplit(T, B);
 }
 
@@ -377,6 +530,17 @@ extern "C" int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64
   FST_REQUIRE(nce_sum, "fst_cpc_nce_fwd: nce_sum is null");
   FST_REQUIRE(p.n_panels == 1 || ws, "fst_cpc_nce_fwd: %d columns = %d panels need the workspace (fst_cpc_workspace_floats)", Bc,
               p.n_panels);
+  if (p.n_panels == 1 && cpc_gram_bf3_ok(T, B, C, Bc)) {
+    FST_REQUIRE(ws, "fst_cpc_nce_fwd: the split-bf16 forward needs the workspace (fst_cpc_workspace_floats: enc_t [T][B][C])");
+    const size_t gram_lds = 4 * (size_t)CG_IMG + 3 * 8 * 32 * sizeof(float);
+    if (int rc = fst_allow_full_lds((const void*)cpc_gram_bf3_kernel, "fst_cpc_nce_fwd")) return rc;
+    hipLaunchKernelGGL(cpc_enc_gather_kernel, dim3((unsigned)((B * C + 63) / 64), (unsigned)((T + 31) / 32)), dim3(256), 0,
+                       (hipStream_t)stream, p, ws);
+    FST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cpc_gram_bf3_kernel, dim3((unsigned)T), dim3(512), gram_lds, (hipStream_t)stream, p, (const float*)ws);
+    FST_LAUNCH_CHECK();
+    return 0;
+  }
   if (lds_bytes > 48 * 1024)
     if (int rc = fst_allow_full_lds((const void*)cpc_fwd_kernel, "fst_cpc_nce_fwd")) return rc;
   const int ysplit = cpc_fwd_ysplit(T, B);

@@ -1826,8 +1826,8 @@ class CPCNceFn(torch.autograd.Function):
         assert t0_host + T <= L
         lse = torch.empty(T, B, device=feat.device, dtype=torch.float32)
         # one partial sum per workgroup, added here in slot order (deterministic; float atomics into one scalar were not)
-        acc = torch.empty(lib.fst_cpc_nce_slots(T, B, Bc), device=feat.device, dtype=torch.float32)
-        n_ws = lib.fst_cpc_workspace_floats(T, B, Bc)                          # > 256 negatives: per-panel softmax statistics
+        acc = torch.empty(lib.fst_cpc_nce_slots(T, B, C, Bc), device=feat.device, dtype=torch.float32)
+        n_ws = lib.fst_cpc_workspace_floats(T, B, C, Bc)      # the transposed encodings [T, B, C]; > 256 negatives: per-panel softmax statistics
         ws = torch.empty(n_ws, device=feat.device, dtype=torch.float32) if n_ws else None
         check(lib.fst_cpc_nce_fwd(feat.data_ptr() + 4 * t0_host, 1, C * L, L, ptr(t0_dev), ptr(pred), T, B, C, Bc, col_off,
                                   ptr(lse), ptr(acc), ptr(ws), stream_ptr()), "fst_cpc_nce_fwd")

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 10
+#define FST_ABI_VERSION 11
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -370,13 +370,15 @@ int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, con
  * Rows (B encodings of this rank) and columns (Bc predictions) may differ: "global batch" data parallelism scores
  * the local rows against the predictions gathered from every rank, the positives at columns col_off + b.
  * ------------------------------------------------------------------------------------------- */
-/* More than 256 columns are processed as panels of 256: the forward then needs a workspace of
- * fst_cpc_workspace_floats(T, B, Bc) floats (0 for Bc <= 256) for the per-panel softmax statistics, and the backward
+/* Up to 256 columns and 64 channels (split-bf16 arithmetic): the forward transposes the T steps it reads into a workspace
+ * [T][B][C] (whole lines in, whole lines out) and runs the cross-Gram on v_mfma_f32_32x32x16_bf16 with hi/lo operands (ABI v11).
+ * More than 256 columns are processed as panels of 256: the forward then needs a workspace of
+ * fst_cpc_workspace_floats(T, B, C, Bc) floats for the per-panel softmax statistics, and the backward
  * accumulates denc across panels with fp32 atomics (the caller zero-fills denc — it must anyway outside [t0, t0+T)). */
-int64_t fst_cpc_workspace_floats(int T, int B, int Bc);
+int64_t fst_cpc_workspace_floats(int T, int B, int C, int Bc);
 /* nce_sum is an array of fst_cpc_nce_slots(T, B, Bc) partial sums, one per workgroup, every slot written (no zero fill): the
  * caller adds them in slot order, so the loss is bit-identical from run to run (ABI v9; a zeroed scalar fed by float atomics before). */
-int64_t fst_cpc_nce_slots(int T, int B, int Bc);
+int64_t fst_cpc_nce_slots(int T, int B, int C, int Bc);
 int fst_cpc_nce_fwd(const float* enc, int64_t s_i, int64_t s_b, int64_t s_c, const int32_t* t0_dev /* optional */,
                     const float* pred /* [T][Bc][C] */, int T, int B, int C,
                     int Bc /* columns = negatives; = B on one GPU */, int col_off /* column of row 0's positive */,
