@@ -227,17 +227,22 @@ def north_star_extras(fst, ops, trainer, x_t, B: int, L: int):
         out["omni_scale_fe_forward"] = {
             "ms": ms, "algorithmic_GBps": 4.0 * (C_in + C) * B * L / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
             "TFLOPps": 2.0 * macs * B * L / (ms * 1e-3) / 1e12,
-            "counters": "profiles/r03_north_star_micro_hbm_traffic.csv, profiles/r03_north_star_micro_mfma_busy.csv (rocprofv3 --pmc passes on tools/north_star_micro.py)",
+            "counters": "profiles/r04_north_star_micro_hbm_traffic.csv, profiles/r04_north_star_micro_mfma_busy.csv (rocprofv3 --pmc passes on tools/north_star_micro.py)",
             "note": "OS_CNN_res forward incl. train-mode BatchNorm passes; layer 1 (216 900 live MACs/timestep) runs on "
-                    "conv_win_bf3_kernel — see roofline.kernels for its own rate; the block is compute-bound, the GB/s "
+                    "conv_win_rows_kernel / conv_win_bf3_kernel — see roofline.kernels for its own rate; the block is compute-bound, the GB/s "
                     "figure is input + features once"}
         feat = torch.randn(B, C, L, device=x_t.device)
         T = L // 2
         pred = torch.randn(T, B, C, device=x_t.device) * 0.3
         ms = _timed(lambda: ops.CPCNceFn.apply(feat, pred, 7, T))
-        out["cpc_cross_gram"] = {"ms": ms, "counters": "profiles/r03_north_star_micro_hbm_traffic.csv, profiles/r03_north_star_micro_mfma_busy.csv", "TFLOPps": 2.0 * T * B * B * C / (ms * 1e-3) / 1e12, "peak_TFLOPps": 157.3,
-                                 "note": "all T cross-Grams enc_i·pred_iT (K = C = 50) on v_mfma_f32_32x32x2_f32 (exact fp32), "
-                                         "log-softmax + diagonal fused on the accumulators; priced against the f32 MFMA peak"}
+        out["cpc_cross_gram"] = {"ms": ms, "counters": "profiles/r04_north_star_micro_hbm_traffic.csv, profiles/r04_north_star_micro_mfma_busy.csv", "TFLOPps": 2.0 * T * B * B * C / (ms * 1e-3) / 1e12,
+                                 "peak_TFLOPps": BF16X3_MFMA_PEAK_TFLOPS if ops.MATH == "bf16x3" else F32_MFMA_PEAK_TFLOPS,
+                                 "note": ("all T cross-Grams enc_i·pred_iT (K = C = 50 padded to 64): a transposing gather of the encodings + one "
+                                          "workgroup per step on v_mfma_f32_32x32x16_bf16 with split operands (hi*hi + hi*lo + lo*hi), log-softmax + "
+                                          "diagonal on the accumulators of the transposed tile; ms = both launches + the 256-slot loss sum; priced "
+                                          "against the split-bf16 MFMA peak; counters: 54 MB moved for 39 MB of operands, MFMA-busy 0.09")
+                                 if ops.MATH == "bf16x3" else
+                                 "all T cross-Grams on v_mfma_f32_32x32x2_f32 (exact fp32); priced against the f32 MFMA peak"}
         rl = trainer.random_layer
         xf = torch.randn(B, C * L, device=x_t.device)
         R0, R1 = rl.random_matrix[0], rl.random_matrix[1]
@@ -250,7 +255,7 @@ def north_star_extras(fst, ops, trainer, x_t, B: int, L: int):
             "ms": ms, "TFLOPps": 2.0 * B * C * L * R0.size(1) / (ms * 1e-3) / 1e12,
             "algorithmic_GBps": 4.0 * (R0.numel() + xf.numel() + B * R0.size(1)) / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
             "matrix_GBps": 4.0 * R0.numel() / (ms * 1e-3) / 1e9, "data_gradient_ms": ms_b,
-            "counters": "profiles/r03_north_star_micro_hbm_traffic.csv, profiles/r03_north_star_micro_mfma_busy.csv",
+            "counters": "profiles/r04_north_star_micro_hbm_traffic.csv, profiles/r04_north_star_micro_mfma_busy.csv",
             "note": "RandomLayer.forward as ONE GEMM: 256 x 25600 x 1024 on the time-as-k kernel (fst_nt_gemm: split-bf16 MFMA, both "
                     "operands row-major with K contiguous, the 105 MB fixed matrix read once by the LDS-DMA ring, K split into 32 "
                     "partial slabs added in a fixed order - no atomics) with the class-side product, the 1/sqrt(1024) scale and the "
