@@ -141,6 +141,30 @@ expect(lib.fst_wn_layer_fwd(P(a1), n * Lq, P(u1), h * Lq, P(img), img_b - 16, P(
                             Bq * n * Lq, None), "bad", "fst_wn_layer_fwd (short image)")
 expect(lib.fst_wn_layer_fwd(P(a1), n * Lq, P(u1), h * Lq, P(img), img_b, P(ts1), None, P(an1), P(out1), 1, 0, Bq, Lq, n, h, 4,
                             Bq * n * Lq + 1, None), "bad", "fst_wn_layer_fwd (element count)")
+# the whole stack's backward: HOST tables of per-layer device pointers walked before the one launch
+nl = 8
+imgb = [buf(lib.fst_wn_bwd_image_bytes(n, int(i == nl - 1)) // 4) for i in range(nl)]
+imgd = [buf(lib.fst_wn_dgrad_image_bytes(n) // 4) for _ in range(nl)]
+tss = [buf(Bq * 2 * n * Lq) for _ in range(nl)]
+dgs = [buf(Bq * 2 * n * Lq) for _ in range(nl)]
+das = [buf(Bq * n * Lq) for _ in range(nl)]
+rsb, rsd = [buf(256 * Bq) for _ in range(nl)], [buf(128 * Bq) for _ in range(nl)]
+d_out1, du1 = buf(Bq * n * Lq), buf(Bq * h * Lq)
+tab = lambda ts: (ctypes.c_void_p * len(ts))(*[P(t) for t in ts])
+assert lib.fst_wn_stack_bwd_ok(n, h, Lq, nl) == 1 and lib.fst_wn_stack_bwd_ok(n, h, 1024, nl) == 0 and lib.fst_wn_stack_bwd_ok(n, h, Lq, 11) == 0
+expect(lib.fst_wn_stack_bwd(tab(tss), tab(imgb), tab(imgd), tab(dgs), tab(das), tab(rsb), tab(rsd), P(d_out1), P(du1), h * Lq, nl, Bq, Lq,
+                            n, h, Bq * n * Lq, None), "launch", "fst_wn_stack_bwd (full pass: every layer's dg / d_a kept)")
+scratch = [das[0]] + [None] * (nl - 1)
+expect(lib.fst_wn_stack_bwd(tab(tss), tab(imgb), tab(imgd), tab([dgs[0]] * nl), tab(scratch), None, None, P(d_out1), P(du1), h * Lq, nl,
+                            Bq, Lq, n, h, Bq * n * Lq, None), "launch", "fst_wn_stack_bwd (partial pass: scratch dg, only layer 0's d_a)")
+expect(lib.fst_wn_stack_bwd(tab(tss), tab(imgb), tab(imgd), tab(dgs), tab([None] * nl), None, None, P(d_out1), P(du1), h * Lq, nl, Bq, Lq,
+                            n, h, Bq * n * Lq, None), "bad", "fst_wn_stack_bwd (layer 0's d_a missing)")
+expect(lib.fst_wn_stack_bwd(tab(tss), tab(imgb), tab(imgd), tab(dgs), tab(das), tab(rsb), None, P(d_out1), P(du1), h * Lq, nl, Bq, Lq,
+                            n, h, Bq * n * Lq, None), "bad", "fst_wn_stack_bwd (one row-sum table only)")
+expect(lib.fst_wn_stack_bwd(tab(tss), tab(imgb), tab(imgd), tab(dgs), tab(das), None, None, P(d_out1), P(du1), h * Lq - 4, nl, Bq, Lq,
+                            n, h, Bq * n * Lq, None), "bad", "fst_wn_stack_bwd (d_u0 batch stride smaller than a sample)")
+assert lib.fst_cpc_nce_slots(256, 256, 50, 256) == 256 and lib.fst_cpc_workspace_floats(256, 256, 50, 256) == 256 * 256 * 50
+assert lib.fst_cpc_workspace_floats(8, 16, 50, 512) == 8 * 16 * 2 * 3
 print("fused WN layer launchers")
 
 # ---- 5. NoiseTransfer / BatchNorm / row sums: shape checks
