@@ -178,7 +178,8 @@ extern "C" int fst_wn_pack(const float* in_w, const float* cond_w, const float* 
 
 // Diagnostic builds only (tools/build_wn_exp.sh): WN_EXP is a bit mask that removes one cost at a time from the fused
 // forward kernel (wrong results, timing only): 1 no MFMAs, 2 B pieces from the zero block (no activation fetch), 4 A pieces
-// from the zero block (no weight fetch), 8 no t,s / acts stores, 16 no final epilogue, 32 no B fragment reads / split.
+// from the zero block (no weight fetch), 8 no t,s / acts stores, 16 no final epilogue, 32 no B fragment reads / split, 64 no skip half
+// (no load / store of the running skip sum, no skip-row MFMAs in GEMM 2: what a deferred skip GEMM would leave in this kernel).
 #ifndef WN_EXP
 #define WN_EXP 0
 #endif
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
     {
       const int rows_e = (WN_EXP & 16) ? 0 : n - blk * 32;
       wn_acc_load(acc[blk], ab + (long long)(blk * 32) * L, p.last ? 0 : rows_e, L, tcol, lane);
-      wn_acc_load(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, p.first ? 0 : rows_e, L, tcol, lane);
+      wn_acc_load(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, (p.first || (WN_EXP & 64)) ? 0 : rows_e, L, tcol, lane);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
     const char* base = ldsb + slot * F_SLOT;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
-      if (!(p.last && mb < 4)) {                       // wave-uniform
+      if (!(p.last && mb < 4) && !((WN_EXP & 64) && mb >= 4)) {                       // wave-uniform
         const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
         const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
         if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh2[ks]), "v"(bl2[ks])); }
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
   for (int blk = 0; blk < ((WN_EXP & 16) ? 0 : 4); ++blk) {
     const int rows_e = n - blk * 32;
     if (!p.last) wn_acc_store(acc[blk], p.a_next + ((long long)b * n + blk * 32) * L, rows_e, L, tcol, lane);
-    wn_acc_store(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, rows_e, L, tcol, lane);
+    if (!(WN_EXP & 64)) wn_acc_store(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, rows_e, L, tcol, lane);
   }
   WN_T(tg3);
   WN_ACC(8, tg2, tg3);                                 // final epilogue (issue; includes waiting for the operand loads)
