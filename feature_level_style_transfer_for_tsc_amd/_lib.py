@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _LIB_NAME = "libfst_hip.so"
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FST_HIP_LIB", os.path.join(_HERE, _LIB_NAME))     # override: diagnostic builds only
@@ -72,6 +72,10 @@ _SIGNATURES = {
     "fst_dense_tap_wgrad_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "fst_dense_tap_wgrad": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "fst_relu_bwd": (c_int, [_P, _P, _P, c_int64, c_void_p]),
+    "fst_gemm_workspace_floats": (c_int64, [c_int, c_int, c_int]),
+    "fst_gemm": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int, c_int, c_int, _P, c_int, c_float, _P, c_int64,
+                         c_void_p]),
+    "fst_act_bwd": (c_int, [_P, _P, _P, c_int64, c_float, c_void_p]),
     "fst_batch_sum": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_void_p]),
     "fst_noise_transfer_fwd": (c_int, [_P, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_void_p]),
     "fst_bcast_add": (c_int, [_P, _P, _P, c_int, c_int64, c_void_p]),

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
     {
       const int rows_e = (WN_EXP & 16) ? 0 : n - blk * 32;
       wn_acc_load(acc[blk], ab + (long long)(blk * 32) * L, p.last ? 0 : rows_e, L, tcol, lane);
-      wn_acc_load(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, (p.first || (WN_EXP & 64)) ? 0 : rows_e, L, tcol, lane);
+      wn_acc_load(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, ((p.first != 0) | ((WN_EXP & 64) != 0)) ? 0 : rows_e, L, tcol, lane);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {

@@ -643,26 +643,83 @@ class ConvReluFn(torch.autograd.Function):
         return None, dx, dw, db
 
 
-class LinearReluFn(torch.autograd.Function):
-    """relu(x @ Wᵀ + b) over the last dimension, bias and ReLU in the hipBLASLt epilogue (one kernel: DimensionUnification's length
-    GEMM, widgets.py:73-75; a plain library GEMM, as the hot-path rules allow)."""
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2       # FST_ACT_* of include/fst_hip.h
+
+
+def gemm_ok(*ts: Tensor) -> bool:
+    """Whether ``gemm`` serves these operands: split-bf16 mode, fp32 on the GPU (any shape, any row pitch)."""
+    return MATH == "bf16x3" and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 for t in ts)
+
+
+def gemm(A: Tensor, ta: bool, B: Tensor, tb: bool, bias: Optional[Tensor] = None, act: int = ACT_NONE, slope: float = 0.0) -> Tensor:
+    """C[m, n] = act(Σ_k A(m,k)·B(n,k) + bias[n]) on the matrix cores in split-bf16 (fst_gemm).  ``A`` is a row-major matrix holding
+    A(m,k) at [m, k] (``ta`` False) or at [k, m] (``ta`` True: the reduction index runs down the rows); ``B`` likewise with B(n,k) —
+    Linear forward ``gemm(x, False, W, False, b)``, its data gradient ``gemm(g, False, W, True)``, its weight gradient
+    ``gemm(g, True, x, True)``: no transposed copies.  K splits land in slabs added in a fixed order (deterministic)."""
+    if not gemm_ok(A, B):
+        raise ValueError(f"gemm: operands {tuple(A.shape)} / {tuple(B.shape)} must be fp32 matrices with unit column stride on the GPU "
+                         f"(split-bf16 mode; FST_MATH={MATH})")
+    lib = _lib.load()
+    K, M = (A.shape if ta else A.shape[::-1])
+    Kb, N = (B.shape if tb else B.shape[::-1])
+    if K != Kb or (bias is not None and (bias.numel() != N or not bias.is_contiguous())):
+        raise ValueError(f"gemm: A {tuple(A.shape)} (ta={ta}) and B {tuple(B.shape)} (tb={tb}) do not share a reduction length, or bias is not [N]")
+    C = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    ws_n = lib.fst_gemm_workspace_floats(M, N, K)
+    ws = torch.empty(ws_n, device=A.device, dtype=torch.float32) if ws_n > 0 else None
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_gemm(ptr(A), A.stride(0), int(ta), ptr(B), B.stride(0), int(tb), ptr(C), N, M, N, K, ptr(bias), act, float(slope),
+                       ptr(ws), ws_n, stream_ptr()), "fst_gemm")
+    if t0 is not None:
+        KERNEL_TIMER.end("gemm_bf3_kernel bf3", t0, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N))
+    return C
+
+
+def act_bwd(dy: Tensor, y: Tensor, slope: float) -> Tensor:
+    """dy·act'(y) from the activation's output: dy where y > 0, slope·dy elsewhere (ReLU: slope 0)."""
+    dy = dy.contiguous()
+    out = torch.empty_like(dy)
+    check(_lib.load().fst_act_bwd(ptr(dy), ptr(y), ptr(out), _same_numel(dy, y), float(slope), stream_ptr()), "fst_act_bwd")
+    return out
+
+
+class LinearActFn(torch.autograd.Function):
+    """act(x @ Wᵀ + b) over the last dimension — nn.Linear (+ nn.ReLU / nn.LeakyReLU) of the heads (DimensionUnification's length
+    GEMM widgets.py:73-75, the CDAN discriminator :113-131, FeatureDiscriminatorforSource :32-42, the classifiers' last layer
+    OS_CNN.py:268): bias and activation in the GEMM's epilogue, the three products of the layer on fst_gemm without transposed copies."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, W: Tensor, b: Tensor):
-        x2 = x.reshape(-1, x.size(-1)).contiguous()
-        y = torch._addmm_activation(b, x2, W.t(), use_gelu=False)
-        ctx.save_for_backward(x2, W, y)
-        ctx.lead = x.shape[:-1]
+    def forward(ctx, x: Tensor, W: Tensor, b: Optional[Tensor], act: int, slope: float):
+        x2 = x.reshape(-1, x.size(-1))
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        y = gemm(x2, False, W, False, b, act, slope)
+        ctx.save_for_backward(x2, W, y if act != ACT_NONE else None)
+        ctx.lead, ctx.act, ctx.slope, ctx.has_bias = x.shape[:-1], act, slope, b is not None
         return y.view(*ctx.lead, W.size(0))
 
     @staticmethod
     def backward(ctx, dy):
         x2, W, y = ctx.saved_tensors
-        g = relu_bwd(dy.reshape(y.shape), y)
-        dx = (g @ W).view(*ctx.lead, W.size(1)) if ctx.needs_input_grad[0] else None
-        dW = g.t() @ x2 if ctx.needs_input_grad[1] and _want_weight_grad() else None
-        db = g.sum(dim=0) if ctx.needs_input_grad[2] and _want_weight_grad() else None
-        return dx, dW, db
+        g = dy.reshape(-1, W.size(0))
+        g = act_bwd(g, y, ctx.slope if ctx.act == ACT_LEAKY else 0.0) if ctx.act != ACT_NONE else g.contiguous()
+        dx = gemm(g, False, W, True).view(*ctx.lead, W.size(1)) if ctx.needs_input_grad[0] else None
+        dW = gemm(g, True, x2, True) if ctx.needs_input_grad[1] and _want_weight_grad() else None
+        db = g.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] and _want_weight_grad() else None
+        return dx, dW, db, None, None
+
+
+def linear_act(x: Tensor, lin: "torch.nn.Linear", act: int = ACT_NONE, slope: float = 0.0) -> Tensor:
+    """``act(lin(x))``: on fst_gemm in split-bf16 mode; with FST_MATH=f32 the library's exact-f32 GEMM and the aten activation, as the
+    reference runs them."""
+    if x.is_cuda and x.dtype == torch.float32 and MATH == "bf16x3":
+        return LinearActFn.apply(x, lin.weight, lin.bias, act, slope)
+    h = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    if act == ACT_RELU:
+        return torch.nn.functional.relu(h)
+    if act == ACT_LEAKY:
+        return torch.nn.functional.leaky_relu(h, slope)
+    return h
 
 
 def mask_taps_(w: Tensor, lo: Tensor, hi: Tensor) -> None:

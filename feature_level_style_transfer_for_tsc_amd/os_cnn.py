@@ -157,7 +157,7 @@ class OS_CNN(nn.Module):
             X = layer(X)
         X_f = X.mean(dim=-1)
         if not self.few_shot:
-            X = self.hidden(X_f)
+            X = ops.linear_act(X_f, self.hidden)
         return X, X_f
 
 

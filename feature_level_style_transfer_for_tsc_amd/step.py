@@ -339,7 +339,7 @@ class JointTrainer:
         ce_t, ce_s = F.cross_entropy(logit_t, y_t), F.cross_entropy(logit_s, y_s)
         cdan = CDAN(feat_t, feat_s2t, logit_t, logit_s2t, m["ad_net"], self.random_layer)
         tr_t, tr_s2t = m["probtransfer"](pool_t), m["probtransfer"](pool_s2t)
-        ce_s2t2s = F.cross_entropy(m["clf_s"].hidden(tr_s2t), y_s)
+        ce_s2t2s = F.cross_entropy(ops.linear_act(tr_s2t, m["clf_s"].hidden), y_s)
         fd = wgan_loss(m["fd_s"](tr_t), m["fd_s"](tr_s2t), m["fd_s"](pool_s))
         main.wait_stream(self._side)
         for t in (feat_t, feat_s):                                             # consumed on the side stream too

@@ -44,7 +44,12 @@ class FeatureDiscriminatorforSource(nn.Module, _GRLCounter):
         coeff = self._next_coeff()
         probs = probs * 1.0
         probs.register_hook(grl_hook(coeff))
-        return self.model(probs)
+        m = self.model
+        # Linear + LeakyReLU pairs as one GEMM each (bias and activation in its epilogue)
+        h = ops.linear_act(probs, m[0], ops.ACT_LEAKY, m[1].negative_slope)
+        h = ops.linear_act(h, m[2], ops.ACT_LEAKY, m[3].negative_slope)
+        h = ops.linear_act(h, m[4], ops.ACT_LEAKY, m[5].negative_slope)
+        return ops.linear_act(h, m[6])
 
 
 class ProbTransfer(nn.Module):
@@ -85,7 +90,7 @@ class DimensionUnification(nn.Module):
     def forward(self, source_feature):
         if source_feature.is_cuda and source_feature.dtype == torch.float32:
             # both ReLUs in the epilogues of their GEMMs: two launches for the module
-            h = ops.LinearReluFn.apply(source_feature, self.length_unification.weight, self.length_unification.bias)
+            h = ops.linear_act(source_feature, self.length_unification, ops.ACT_RELU)
             return ops.ConvReluFn.apply(self.spec, h, self.channel_unification.weight, self.channel_unification.bias)
         h = self.relu1(self.length_unification(source_feature))
         h = ops.conv1d(self.spec, h.contiguous(), self.channel_unification.weight, self.channel_unification.bias)
@@ -122,9 +127,9 @@ class AdversarialNetworkforCDAN(nn.Module, _GRLCounter):
         self.coeff = coeff
         x = x * 1.0
         x.register_hook(grl_hook(coeff))
-        x = self.dropout1(self.relu1(self.ad_layer1(x)))
-        x = self.dropout2(self.relu2(self.ad_layer2(x)))
-        return self.ad_layer3(x)
+        x = self.dropout1(ops.linear_act(x, self.ad_layer1, ops.ACT_RELU))
+        x = self.dropout2(ops.linear_act(x, self.ad_layer2, ops.ACT_RELU))
+        return ops.linear_act(x, self.ad_layer3)
 
 
 class NoiseTransfer(nn.Module):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FST_ABI_VERSION 11
+#define FST_ABI_VERSION 12
 
 int fst_version(void);
 const char* fst_last_error(void);
@@ -356,6 +356,25 @@ int fst_noise_transfer_bwd_apply(const float* g, const float* dd, const float* r
 
 /* generic fp32 elementwise helpers on contiguous buffers */
 int fst_relu_bwd(const float* dy, const float* y, float* out, int64_t n, void* stream);   /* out = dy·[y > 0] (epilogue-fused ReLUs) */
+
+/* Dense products of the small heads on the matrix cores in split-bf16 — replaces the aten addmm / mm calls behind
+ * /root/reference/widgets.py:73-75 (DimensionUnification.length_unification: [B·C_s, L_s] × [L_t, L_s]ᵀ + ReLU), :113-131
+ * (AdversarialNetworkforCDAN's Linear-ReLU chain), :32-42 (FeatureDiscriminatorforSource's Linear-LeakyReLU chain) and their gradients:
+ *     C[m][n] = act( Σ_k A(m,k)·B(n,k) + bias[n] ),   m < M, n < N, k < K,   C row-major with row pitch ldc
+ * ta = 0: A(m,k) = A[m·lda + k] (reduction index contiguous);  ta = 1: A(m,k) = A[k·lda + m] (reduction index major);  tb likewise for
+ * B(n,k) — so   y = x·Wᵀ is (x, 0, W, 0),   dx = g·W is (g, 0, W, 1),   dW = gᵀ·x is (g, 1, x, 1),   no transposed copies.
+ * Any M, N, K and pitches; 16-byte loads where rows allow them.  K is split across workgroups when the tiles alone do not fill the
+ * chip: partial tiles go to `workspace` (fst_gemm_workspace_floats, 0 when no split is used) and are added in a fixed order — the
+ * same bits on every run.  bias (may be NULL) is per output column; act = FST_ACT_*, slope = LeakyReLU's negative slope. */
+#define FST_ACT_NONE  0
+#define FST_ACT_RELU  1
+#define FST_ACT_LEAKY 2
+int64_t fst_gemm_workspace_floats(int M, int N, int K);
+int fst_gemm(const float* A, int64_t lda, int ta, const float* B, int64_t ldb, int tb, float* C, int64_t ldc, int M, int N, int K,
+             const float* bias, int act, float slope, float* workspace, int64_t workspace_floats, void* stream);
+/* out = dy·act'(y) from the activation's output y: dy where y > 0, slope·dy elsewhere (slope = 0: ReLU) — nn.ReLU / nn.LeakyReLU backward
+ * behind an activation that ran in fst_gemm's epilogue. */
+int fst_act_bwd(const float* dy, const float* y, float* out, int64_t n, float slope, void* stream);
 int fst_axpy(float* y, const float* x, float alpha, int64_t n, void* stream);          /* y += alpha*x */
 int fst_add_slices(float* dst, int64_t dst_bs, const float* a, int64_t a_bs, const float* b, int64_t b_bs,
                    int B, int C, int L, void* stream);                                  /* dst = a + b (b may be null) */

@@ -117,16 +117,18 @@ def _head_unit_branches(record=None, impose=None, flips=None):
             record.append((out.detach() > 0).cpu())
             return out
         _ops.BNActFn.apply, _ops.BNAddBNReluFn.apply = bn_act_rec, bn_join_rec
-        # the dimension unification's two ReLUs run in the epilogues of its GEMM and of its 1x1 conv
-        lin_relu, conv_relu = _ops.LinearReluFn.apply, _ops.ConvReluFn.apply
+        # the heads' ReLU / LeakyReLU layers run in the epilogues of their GEMMs (LinearActFn: out > 0 <=> pre-activation > 0
+        # for both), the dimension unification's second ReLU in the epilogue of its 1x1 conv
+        lin_act, conv_relu = _ops.LinearActFn.apply, _ops.ConvReluFn.apply
 
-        def epi_rec(fn):
+        def epi_rec(fn, act_arg=None):
             def wrapped(*a):
                 out = fn(*a)
-                record.append((out.detach() > 0).cpu())
+                if act_arg is None or a[act_arg] != _ops.ACT_NONE:
+                    record.append((out.detach() > 0).cpu())
                 return out
             return wrapped
-        _ops.LinearReluFn.apply, _ops.ConvReluFn.apply = epi_rec(lin_relu), epi_rec(conv_relu)
+        _ops.LinearActFn.apply, _ops.ConvReluFn.apply = epi_rec(lin_act, 3), epi_rec(conv_relu)
     try:
         yield
         if it is not None:
@@ -135,7 +137,7 @@ def _head_unit_branches(record=None, impose=None, flips=None):
         F.relu, F.leaky_relu, R.dimension_unification = relu0, leaky0, dimunif0
         if record is not None:
             del _ops.BNActFn.apply, _ops.BNAddBNReluFn.apply       # back to the inherited Function.apply
-            del _ops.LinearReluFn.apply, _ops.ConvReluFn.apply
+            del _ops.LinearActFn.apply, _ops.ConvReluFn.apply
 
 
 def _step_both(js, tr, batch, ts):

@@ -617,7 +617,7 @@ def test_wn_other_depths_and_kernel_sizes_vs_oracle(n_layers, kernel, fused_expe
 
 
 def test_dimension_unification_fused_relus_vs_composition():
-    """DimensionUnification with both ReLUs in the GEMM / conv epilogues (ops.LinearReluFn, ops.ConvReluFn) against the reference's
+    """DimensionUnification with both ReLUs in the GEMM / conv epilogues (ops.LinearActFn, ops.ConvReluFn) against the reference's
     composition relu(conv1x1(relu(linear(x)))) (widgets.py:66-78) in fp64: output and every gradient."""
     torch.manual_seed(5)
     du = fst.DimensionUnification(25, 50, 96, 64).to(DEV)
