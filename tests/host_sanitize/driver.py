@@ -175,4 +175,25 @@ expect(lib.fst_batch_sum(P(buf(16 * C * Ln)), None, P(part), 16, C * Ln + 2, 8, 
 expect(lib.fst_row_sum(P(buf(4 * 8 * 16)), 8 * 16, 4, 8, 16, P(buf(8)), None), "launch", "fst_row_sum")
 expect(lib.fst_row_sum(P(buf(4 * 8 * 16)), 8 * 16 - 1, 4, 8, 16, P(buf(8)), None), "bad", "fst_row_sum (stride)")
 print("pointwise launchers")
+
+# ---- 6. fst_gemm: leading dimensions per layout, activation code, the K-split workspace
+x, w, y = buf(256 * 1024), buf(1024 * 1024), buf(256 * 1024)
+ws_n = lib.fst_gemm_workspace_floats(256, 1024, 1024)
+assert ws_n == 0 or ws_n % (256 * 1024) == 0
+ws = buf(max(ws_n, 4))
+expect(lib.fst_gemm(P(x), 1024, 0, P(w), 1024, 0, P(y), 1024, 256, 1024, 1024, P(buf(1024)), 1, 0.0, P(ws), ws_n, None), "launch",
+       "fst_gemm (y = x Wt + b, ReLU)")
+expect(lib.fst_gemm(P(y), 1024, 0, P(w), 1024, 1, P(x), 1024, 256, 1024, 1024, None, 0, 0.0, P(ws), ws_n, None), "launch", "fst_gemm (dx = g W)")
+expect(lib.fst_gemm(P(y), 1024, 1, P(x), 1024, 1, P(w), 1024, 1024, 1024, 256, None, 0, 0.0, P(ws), lib.fst_gemm_workspace_floats(1024, 1024, 256),
+                    None), "launch", "fst_gemm (dW = gt x)")
+expect(lib.fst_gemm(P(x), 50, 0, P(w), 50, 0, P(y), 1, 256, 1, 50, None, 2, 0.2, None, 0, None), "launch", "fst_gemm (one output column, K % 4 != 0)")
+expect(lib.fst_gemm(P(x), 512, 0, P(w), 1024, 0, P(y), 1024, 256, 1024, 1024, None, 0, 0.0, P(ws), ws_n, None), "bad", "fst_gemm (lda < K)")
+expect(lib.fst_gemm(P(y), 128, 1, P(x), 1024, 1, P(w), 1024, 1024, 1024, 256, None, 0, 0.0, P(ws), ws_n, None), "bad", "fst_gemm (k-major lda < M)")
+expect(lib.fst_gemm(P(x), 1024, 0, P(w), 1024, 0, P(y), 512, 256, 1024, 1024, None, 0, 0.0, P(ws), ws_n, None), "bad", "fst_gemm (ldc < N)")
+expect(lib.fst_gemm(P(x), 1024, 0, P(w), 1024, 0, P(y), 1024, 256, 1024, 1024, None, 3, 0.0, P(ws), ws_n, None), "bad", "fst_gemm (activation code)")
+if ws_n > 0:
+    expect(lib.fst_gemm(P(x), 1024, 0, P(w), 1024, 0, P(y), 1024, 256, 1024, 1024, None, 0, 0.0, P(ws), ws_n - 1, None), "bad", "fst_gemm (workspace)")
+expect(lib.fst_act_bwd(P(x), P(y), P(buf(256 * 1024)), 256 * 1024, 0.2, None), "launch", "fst_act_bwd")
+expect(lib.fst_act_bwd(P(x), None, P(y), 16, 0.0, None), "bad", "fst_act_bwd (null)")
+print("dense products of the heads")
 print(f"OK: {seen['bad']} argument errors returned, {seen['launch']} launches reached, {seen['value']} size queries")
