@@ -46,7 +46,7 @@ _SIGNATURES = {
     "fst_bn_finalize": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_float, c_float, _P, c_void_p]),
     "fst_bn_apply": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_bn_bwd_reduce": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, c_void_p]),
-    "fst_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
+    "fst_bn_bwd_apply": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_gate_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_gate_bwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_coupling_sum_slots": (c_int64, [c_int, c_int, c_int]),

@@ -395,7 +395,7 @@ __device__ __forceinline__ void bn_red_sums(const float* red, int n_slots, int C
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, const float* y, const float* out,
                                                            const float* stats, const float* red, int n_slots, float* red_out,
-                                                           float* dx, int C, int L, int relu, int train, float invN) {
+                                                           float* dx, float* row_sums, int C, int L, int relu, int train, float invN) {
   const int bc = blockIdx.x;
   const int c = bc % C;
   const float mean = stats[c], invstd = stats[C + c], scale = stats[2 * C + c];
@@ -404,32 +404,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, cons
   if (red_out && bc < C && threadIdx.x == 0) { red_out[c] = r1; red_out[C + c] = r2; }
   const float m1 = train ? r1 * invN : 0.f, m2 = train ? r2 * invN : 0.f;
   const long long base = (long long)bc * L;
+  float rs = 0.f, dummy = 0.f;
   for (int t = threadIdx.x; t < L; t += 256) {
     float g = dy[base + t];
     if (relu && !(out[base + t] > 0.f)) g = 0.f;
     const float xh = (y[base + t] - mean) * invstd;
-    dx[base + t] = scale * (g - m1 - xh * m2);
+    const float d = scale * (g - m1 - xh * m2);
+    dx[base + t] = d;
+    rs += d;
+  }
+  if (row_sums) {                                          // uniform
+    block_sum2(rs, dummy);
+    if (threadIdx.x == 0) row_sums[bc] = rs;
   }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* dy, const float* y, const float* out,
                                                                const float* stats, const float* red, int n_slots,
-                                                               float* red_out, float* dx, int rows, int C, int L, int relu,
-                                                               int train, float invN, RowVec rv) {
+                                                               float* red_out, float* dx, float* row_sums, int rows, int C,
+                                                               int L, int relu, int train, float invN, RowVec rv) {
+  __shared__ float wsum[4];
   const int r = threadIdx.x >> rv.shift, t0 = threadIdx.x & ((1 << rv.shift) - 1), rpp = 256 >> rv.shift;
-  const int bc = blockIdx.x * rpp + r;
-  if (bc >= rows) return;
+  const int bc_raw = blockIdx.x * rpp + r;
+  const bool live = bc_raw < rows;
+  const int bc = live ? bc_raw : rows - 1;                 // (idle row groups of the last block walk the last row and store nothing)
   const int c = bc % C;
   const float mean = stats[c], invstd = stats[C + c], scale = stats[2 * C + c];
   float r1 = 0.f, r2 = 0.f;
   if (red) bn_red_sums(red, n_slots, C, c, r1, r2);
-  if (red_out && bc < C && t0 == 0) { red_out[c] = r1; red_out[C + c] = r2; }
+  if (red_out && live && bc < C && t0 == 0) { red_out[c] = r1; red_out[C + c] = r2; }
   const float m1 = train ? r1 * invN : 0.f, m2 = train ? r2 * invN : 0.f;
   const long long base = (long long)bc * rv.L4;
   const float4* dy4 = reinterpret_cast<const float4*>(dy) + base;
   const float4* y4 = reinterpret_cast<const float4*>(y) + base;
   const float4* o4 = reinterpret_cast<const float4*>(out) + base;
   float4* dx4 = reinterpret_cast<float4*>(dx) + base;
+  float rs = 0.f;
   for (int t = t0; t < rv.L4; t += 1 << rv.shift) {
     float4 g = dy4[t];
     const float4 v = y4[t];
@@ -445,13 +455,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* dy, 
     d.y = scale * (g.y - m1 - (v.y - mean) * invstd * m2);
     d.z = scale * (g.z - m1 - (v.z - mean) * invstd * m2);
     d.w = scale * (g.w - m1 - (v.w - mean) * invstd * m2);
-    dx4[t] = d;
+    if (live) dx4[t] = d;
+    rs += (d.x + d.y) + (d.z + d.w);
+  }
+  // Σ_t dx of this (sample, channel) row — the bias gradient of the conv in front of the BatchNorm is Σ_b of these: the conv's
+  // backward then needs no pass of its own over dx.  A row's 2^shift threads are consecutive: a xor butterfly inside the wave,
+  // then (rows wider than a wave) the waves' totals through LDS in wave order.
+  if (row_sums) {                                          // uniform
+    const int w = rv.shift < 6 ? rv.shift : 6;
+    for (int o = 1 << (w - 1); o > 0; o >>= 1) rs += __shfl_xor(rs, o, 64);
+    if (rv.shift <= 6) {
+      if (live && t0 == 0) row_sums[bc] = rs;
+    } else {
+      if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = rs;
+      __syncthreads();
+      if (live && t0 == 0) {
+        const int w0 = threadIdx.x >> 6, nw = 1 << (rv.shift - 6);
+        float tot = 0.f;
+        for (int i = 0; i < nw; ++i) tot += wsum[w0 + i];
+        row_sums[bc] = tot;
+      }
+    }
   }
 }
 
 extern "C" int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red,
-                                int n_slots, float* red_out, float* dx, int B, int C, int L, int relu, int train, int B_total,
-                                int64_t numel, void* stream) {
+                                int n_slots, float* red_out, float* dx, float* row_sums, int B, int C, int L, int relu, int train,
+                                int B_total, int64_t numel, void* stream) {
   FST_REQUIRE(dy && y && stats && dx && (!relu || out) && (!train || red), "fst_bn_bwd_apply: bad arguments");
   FST_REQUIRE(B > 0 && C > 0 && L > 0 && B_total >= B, "fst_bn_bwd_apply: B=%d C=%d L=%d B_total=%d", B, C, L, B_total);
   FST_REQUIRE(!red || n_slots > 0, "fst_bn_bwd_apply: n_slots=%d", n_slots);
@@ -461,10 +491,10 @@ extern "C" int fst_bn_bwd_apply(const float* dy, const float* y, const float* ou
     const RowVec rv = row_vec(L);
     const int rpp = 256 >> rv.shift;
     hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3((B * C + rpp - 1) / rpp), dim3(256), 0, (hipStream_t)stream, dy, y, out,
-                       stats, red, n_slots, red_out, dx, B * C, C, L, relu, train, 1.0f / ((float)B_total * (float)L), rv);
+                       stats, red, n_slots, red_out, dx, row_sums, B * C, C, L, relu, train, 1.0f / ((float)B_total * (float)L), rv);
   } else {
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, dy, y, out, stats, red, n_slots,
-                       red_out, dx, C, L, relu, train, 1.0f / ((float)B_total * (float)L));
+                       red_out, dx, row_sums, C, L, relu, train, 1.0f / ((float)B_total * (float)L));
   }
   FST_LAUNCH_CHECK();
   return 0;

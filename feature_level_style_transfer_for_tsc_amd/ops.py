@@ -595,6 +595,7 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         spec: ConvSpec = ctx.spec
         x, w = ctx.saved_tensors
+        rs = _ROW_SUMS.take(dy)                                # Σ_t dy per (sample, channel) if the producer of dy left them
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
@@ -602,7 +603,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[2] and _want_weight_grad(spec):
             dw, _ = spec.grad_w(x, None, dy)
         if ctx.has_bias and ctx.needs_input_grad[3] and _want_weight_grad(spec):
-            db = row_sum(dy)
+            db = rs.sum(dim=0) if rs is not None else row_sum(dy)
         return None, dx, dw, db
 
 
@@ -735,6 +736,31 @@ def mask_taps_(w: Tensor, lo: Tensor, hi: Tensor) -> None:
 BN_SLOTS = 16      # FST_BN_SLOTS of include/fst_hip.h: workgroups (= partial results) per channel of the BatchNorm reductions
 
 
+class _RowSums:
+    """Per-(sample, channel) sums Σ_t dx that a backward launch has already formed, handed from the op that produced ``dx`` to the op
+    that consumes it as its output cotangent (BatchNorm backward → the conv in front of it) — as an attribute of the tensor object,
+    which autograd passes on unchanged when the producer is the only contributor to that cotangent.  ``take`` returns them only if
+    the tensor is still the one they were computed from (same object, same version counter, same shape): an accumulated or
+    otherwise rewritten cotangent falls back to the caller's own reduction."""
+
+    @staticmethod
+    def attach(dx: Tensor, rs: Tensor) -> None:
+        dx._fst_row_sums = (rs, dx._version)
+
+    @staticmethod
+    def take(dy: Tensor) -> Optional[Tensor]:
+        tag = getattr(dy, "_fst_row_sums", None)
+        if tag is None or dy.dim() != 3:
+            return None
+        rs, version = tag
+        if version != dy._version or tuple(rs.shape) != tuple(dy.shape[:2]) or not dy.is_contiguous():
+            return None
+        return rs
+
+
+_ROW_SUMS = _RowSums()
+
+
 def _bn_stats(y: Tensor, gamma: Tensor, beta: Tensor, rmean: Tensor, rvar: Tensor, training: bool, eps: float,
               momentum: float) -> Tensor:
     lib = _lib.load()
@@ -767,18 +793,22 @@ def _bn_backward(dy: Tensor, y: Tensor, out: Optional[Tensor], stats: Tensor, re
         red = part.sum(dim=2).view(2 * C)
         return None, red[C:], red[:C]
     dx = torch.empty_like(y)
+    # Σ_t dx per (sample, channel), left by the same launch: the conv in front of this BatchNorm takes its bias gradient from them
+    # (ConvFn.backward) instead of a pass of its own over dx
+    rs = torch.empty(B, C, device=y.device, dtype=torch.float32)
     if training and _dist.global_batch_active():
         # the two batch means of the backward formula run over every rank's samples; the parameter gradients
         # (returned below) stay local sums — the gradient bucket averages them like every other parameter
         red = part.sum(dim=2).view(2 * C)
         red_g = red.clone()
         B_total = _dist.sum_over_ranks_(red_g) * B
-        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(red_g), 1, None, ptr(dx), B, C, L, int(relu),
+        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(red_g), 1, None, ptr(dx), ptr(rs), B, C, L, int(relu),
                                    int(training), B_total, _same_numel(dy, y, out, dx), stream_ptr()), "fst_bn_bwd_apply")
     else:
         red = torch.empty(2 * C, device=y.device, dtype=torch.float32)
-        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(part), BN_SLOTS, ptr(red), ptr(dx), B, C, L,
+        check(lib.fst_bn_bwd_apply(ptr(dy), ptr(y), ptr(out), ptr(stats), ptr(part), BN_SLOTS, ptr(red), ptr(dx), ptr(rs), B, C, L,
                                    int(relu), int(training), B, _same_numel(dy, y, out, dx), stream_ptr()), "fst_bn_bwd_apply")
+    _ROW_SUMS.attach(dx, rs)
     return dx, red[C:], red[:C]                                   # dx, dgamma, dbeta
 
 

@@ -163,10 +163,12 @@ int fst_bn_bwd_reduce(const float* dy, const float* y, const float* out, const f
 /* dx = scale·(dyʹ − r0/N − x̂·r1/N) in train mode, scale·dyʹ in eval mode; r = the n_slots partials of red added in slot order
  * (n_slots = FST_BN_SLOTS as fst_bn_bwd_reduce leaves them, or 1 when the caller has already added them, e.g. over ranks);
  * N = B_total·L.  B is the batch of the tensors (launch shape); B_total >= B the batch red was summed over (= B, or all
- * ranks' batches for SyncBN).  red_out (optional, [2C]): receives (r0 | r1) = (dβ | dγ). */
+ * ranks' batches for SyncBN).  red_out (optional, [2C]): receives (r0 | r1) = (dβ | dγ).  row_sums (optional, [B][C]): receives
+ * Σ_t dx[b][c][t] — summed over b, the bias gradient of the conv in front of the BatchNorm (OS_CNN.py:67-72: conv1d with bias →
+ * BatchNorm1d), which then needs no pass of its own over dx. */
 int fst_bn_bwd_apply(const float* dy, const float* y, const float* out, const float* stats, const float* red, int n_slots,
-                     float* red_out, float* dx, int B, int C, int L, int relu, int train, int B_total, int64_t numel,
-                     void* stream);
+                     float* red_out, float* dx, float* row_sums, int B, int C, int L, int relu, int train, int B_total,
+                     int64_t numel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * WaveGlow pieces — Simplified_NF_WaveGlow.py

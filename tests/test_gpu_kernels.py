@@ -392,9 +392,14 @@ def test_batch_norm_global_batch_arguments_stay_inside_their_buffers():
     _lib.check(lib.fst_bn_bwd_reduce(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), B, C, L, 0, red.data_ptr(), n,
                                      _lib.stream_ptr()), "bn_bwd_reduce")
     red_g = (red.sum(dim=2) * 3).view(2 * C).contiguous()
+    rsum = torch.full((B * C + 2 * PAD,), CANARY, device=DEV)
     _lib.check(lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), 1, None, dx.data_ptr(),
-                                    B, C, L, 0, 1, B_total, n, _lib.stream_ptr()), "bn_bwd_apply")
+                                    rsum[PAD:].data_ptr(), B, C, L, 0, 1, B_total, n, _lib.stream_ptr()), "bn_bwd_apply")
     torch.cuda.synchronize()
+    # the per-(sample, channel) sums of dx the launch leaves for the bias gradient of the conv in front
+    assert bool((rsum[:PAD] == CANARY).all()) and bool((rsum[PAD + B * C:] == CANARY).all()), "row sums: padding was written"
+    rs_err = float((rsum[PAD: PAD + B * C].view(B, C).double() - dx.double().sum(dim=2)).abs().max())
+    assert rs_err <= 1e-5 * float(dx.abs().sum(dim=2).max()), f"row sums of dx: {rs_err:.3e}"
     for name, buf in (("y", ybuf), ("dy", dybuf), ("dx", dxbuf)):
         assert bool((buf[:PAD] == CANARY).all()) and bool((buf[PAD + n:] == CANARY).all()), f"{name}: padding was written"
     # the same formula in fp64: means over the B_total*L global samples (three copies of the local ones)
@@ -405,7 +410,7 @@ def test_batch_norm_global_batch_arguments_stay_inside_their_buffers():
         dyd - dyd.mean(dim=(0, 2), keepdim=True) - xh * (dyd * xh).mean(dim=(0, 2), keepdim=True))
     assert_close(dx, want, 1e-4, "dx with B_total = 3B")
     # (3) the round-1 bug itself — the global batch passed as the launch batch — is now an error return, not a walk
-    rc = lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), 1, None, dx.data_ptr(),
+    rc = lib.fst_bn_bwd_apply(dy.data_ptr(), y.data_ptr(), None, stats.data_ptr(), red_g.data_ptr(), 1, None, dx.data_ptr(), None,
                               B_total, C, L, 0, 1, B_total, n, _lib.stream_ptr())
     assert rc < 0 and b"element count" in lib.fst_last_error()
     rc = lib.fst_bn_apply(y.data_ptr(), stats.data_ptr(), None, None, dx.data_ptr(), B_total, C, L, 0, n, _lib.stream_ptr())

@@ -636,3 +636,47 @@ def test_dimension_unification_fused_relus_vs_composition():
     close(y, want.detach().cpu().numpy(), 1e-5, "dimunif out")
     for a, b, name in zip(got, wg, ["dx"] + [k for k, _ in du.named_parameters()]):
         close(a, b.detach().cpu().numpy(), 1e-4, name)
+
+
+def test_conv_bias_gradient_comes_from_the_batchnorm_backward_launch():
+    """The bias gradient of a conv that feeds a BatchNorm (OS_CNN.py:67-72) is Σ_{b,t} of the BatchNorm's input gradient:
+    fst_bn_bwd_apply leaves the per-(sample, channel) sums, ConvFn.backward adds them over the batch — no row-sum pass of its
+    own over dx (ops.row_sum is not called), same value as that pass; a cotangent that is NOT the BatchNorm's output (here: scaled
+    by an op in between) falls back to the conv's own reduction."""
+    torch.manual_seed(3)
+    g = load("joint_small")
+    meta = json.loads(str(g["meta"]))
+    tup = lambda lp: [[tuple(t) for t in l] for l in lp]
+    fe = fst.OS_CNN_res(tup(meta["lp_t"])).to(DEV)
+    fe.train()
+    x = torch.randn(6, meta["C_in_t"], meta["L_t"], device=DEV)
+    calls, row_sum0 = [], ops.row_sum
+    ops.row_sum = lambda *a, **k: (calls.append(1), row_sum0(*a, **k))[1]
+    try:
+        fe(x).square().sum().backward()
+    finally:
+        ops.row_sum = row_sum0
+    assert not calls, f"{len(calls)} row-sum launches: the BatchNorm backward's sums did not reach the convs"
+    fused = {k: v.grad.clone() for k, v in fe.named_parameters() if k.endswith("conv1d.bias")}
+    assert fused
+    # the same gradients with the hand-over disabled: every conv reduces its own cotangent
+    attach0 = ops._ROW_SUMS.attach
+    summed = []                                            # Σ|dx| per channel: the scale of what each bias gradient sums
+    ops._RowSums.attach = staticmethod(lambda dx, rs: summed.append(float(dx.abs().sum(dim=(0, 2)).max())))
+    try:
+        fe.zero_grad()
+        fe(x).square().sum().backward()
+    finally:
+        ops._RowSums.attach = staticmethod(attach0)
+    for k, v in fe.named_parameters():
+        if k in fused:
+            # both are sums of the same dx in different orders; a bias in front of a BatchNorm has a zero gradient in exact
+            # arithmetic, so compare against the scale of what is summed, not of the (rounding-level) result
+            err = float((fused[k] - v.grad).abs().max())
+            assert err <= 2e-6 * max(summed), (k, err, max(summed))
+    # a rewritten cotangent must not use stale sums
+    dx = torch.randn(4, 5, 32, device=DEV)
+    ops._ROW_SUMS.attach(dx, torch.zeros(4, 5, device=DEV))
+    assert ops._ROW_SUMS.take(dx) is not None
+    dx.mul_(2.0)
+    assert ops._ROW_SUMS.take(dx) is None and ops._ROW_SUMS.take(dx * 1.0) is None

@@ -32,3 +32,14 @@ for name, M, N, K in SHAPES:
     for what, ours, lib in rows:
         a, c = t_us(ours), t_us(lib)
         print(f"{name:12s} M={M:6d} N={N:5d} K={K:5d}  {what}  fst_gemm {a:7.1f} us ({2e-6 * M * N * K / a:6.1f} TFLOP/s)   library {c:7.1f} us")
+
+# RandomLayer (C_DAN.py:21): x [256, 25600] · R0 [25600, 1024] and its data gradient dy [256, 1024] · R0ᵀ
+x, R0, dy = torch.randn(256, 25600, device=dev), torch.randn(25600, 1024, device=dev), torch.randn(256, 1024, device=dev)
+R0t = R0.t().contiguous()
+for what, ours, lib in [("x R0   (R0 k-major)     ", lambda: ops.gemm(x, False, R0, True), lambda: x @ R0),
+                        ("x R0   (R0^T contiguous)", lambda: ops.gemm(x, False, R0t, False), lambda: x @ R0),
+                        ("dy R0^T (R0 rows = n)   ", lambda: ops.gemm(dy, False, R0, False), lambda: dy @ R0.t()),
+                        ("nt_gemm fwd             ", lambda: ops.nt_gemm(x, R0t), lambda: x @ R0),
+                        ("nt_gemm dgrad           ", lambda: ops.nt_gemm(dy, R0), lambda: dy @ R0.t())]:
+    a, c = t_us(ours), t_us(lib)
+    print(f"random layer  {what}  ours {a:7.1f} us   library {c:7.1f} us")
