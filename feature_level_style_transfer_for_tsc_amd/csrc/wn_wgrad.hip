@@ -24,6 +24,7 @@
 // Served: L % 32 == 0, n < 128 (M ≤ 256), h ≤ 32, tap shifts that are multiples of 4 samples (dil % 4 == 0), 16-byte aligned
 // tensors; everything else stays on conv_wgrad_kernel (fst_wn_wgrad_ok tells).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "fst_common.h"
 
@@ -810,6 +811,7 @@ extern "C" int fst_tap_wgrad(const float* dy, const float* x, float* dw, float* 
 // streaming only its own dy rows: dy is then staged by ⌈C/4⌉ channel groups instead of ⌈C/2⌉ (225 × 25 × 89: 551 → … µs).
 #define TZ_CPB 288                                         // bytes per shifted copy: 16 units of 16 B + 32 (16-lane groups then hit all banks)
 #define TZ_XRAW 1024                                       // bytes per staged raw window (40 of 64 pieces used)
+#define TZ_ND 4                                            // ring slots (dy rows and raw windows): multiply c, split c + 1, c + 2 and c + 3 in flight
 
 struct TzParams {
   const float* dy;      // [B][M][L]
@@ -820,7 +822,6 @@ struct TzParams {
   int off0;                     // P4 − pad: window offset of (shift 0, sample t0)
   int n_groups, ksplit, tiles_per_seq, n_tiles, Kcols;
   int m_halves;                 // 1, or 2: workgroup z takes the rows [128·z, min(M, 128·z + 128))
-  int exp;                      // diagnostics (FST_TZ_EXP, timing only, wrong results): 1 no MFMAs, 2 no split pass, 4 no LDS-DMA
 };
 
 __device__ __forceinline__ float tz_lds_read4(const char* p) {
@@ -835,54 +836,123 @@ __device__ __forceinline__ void tz_wait_at_most() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MP>
+#ifndef TZ_EXP
+#define TZ_EXP 0   // diagnostic builds (tools/build_tz_exp.sh; timing only, wrong results): 1 no MFMAs, 2 no split pass, 4 no LDS-DMA,
+#endif             // 8 no fragment reads, 16 no slab stores, 32 no stages
+
+#ifdef TZ_STAMPS
+// Diagnostic build only (tools/build_tz_exp.sh stamps): per-phase s_memtime sums of tz_wgrad_kernel, lane 0 of every wave.
+__device__ unsigned long long tz_stamps[12];
+__device__ __forceinline__ unsigned long long tz_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+extern "C" int fst_debug_tz_stamps(unsigned long long* out_host, int reset) {
+  if (out_host) hipMemcpyFromSymbol(out_host, HIP_SYMBOL(tz_stamps), sizeof(unsigned long long) * 12);
+  if (reset) { unsigned long long z[12] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(tz_stamps), z, sizeof(z)); }
+  return 0;
+}
+#define TZ_T(var) const unsigned long long var = tz_now()
+#define TZ_ACC(slot, a, b) tz_sum[slot] += (b) - (a)
+#define TZ_SUMS unsigned long long tz_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define TZ_FLUSH \
+  if (lane == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&tz_stamps[i_], tz_sum[i_])
+#else
+#define TZ_T(var)
+#define TZ_ACC(slot, a, b)
+#define TZ_SUMS
+#define TZ_FLUSH
+#endif
+
+// LDS accesses by byte address with the constant part of the address as the instruction's immediate offset: the fragment and
+// split-pass reads of a stage share a handful of per-lane address registers (see the instruction budget below)
+template <int OFF>
+__device__ __forceinline__ ww_f32x4 tz_read16(unsigned addr) {
+  ww_f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ float tz_read4(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ void tz_write16(unsigned addr, const ww_u32x4& v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// one LDS-DMA piece: the 64 lanes' 16 bytes land at LDS byte address m0_addr + 16·lane (M0 saved and restored: see ww_dma16)
+__device__ __forceinline__ void tz_dma16(const char* gsrc, unsigned m0_addr) {
+  unsigned saved_m0;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(saved_m0) : "v"(gsrc), "s"(m0_addr) : "memory");
+}
+
+// INSTRUCTION BUDGET.  With two waves per SIMD a wave issues at most one instruction every four cycles and a taken branch costs
+// tens of cycles: a stage of 36 MFMAs (2 × 1152 cycles of matrix pipe per SIMD) leaves room for ≈300 other instructions per wave.
+// The first form of this loop carried 483 (49 branches, 281 scalar) and ran at 5.9 k cycles per stage — an EMPTY loop with its
+// waits, barrier, index divisions and uniform tests alone took 1.4 k (cost removal: profiles/r04_tz_*).  Hence: diagnostics are
+// compile-time (TZ_EXP), the stage position advances by additions (no divisions), every wave issues the same number of pieces
+// per stage (rows beyond the row half re-fetch row 0 — finite values in LDS rows nobody stores — so one counted wait fits all),
+// stages past the end are "virtual" (they re-fetch and re-split the last stage instead of being tested away), FULL drops the
+// block tests around the MFMAs, and LDS addresses are a few per-lane registers plus immediates.
+template <int MP, bool FULL>
 __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
-  constexpr int TZ_CW = 8 / MP;
+  constexpr int CW = 8 / MP;                               // channels per group = waves per row pair
+  constexpr int NDW = MP == 2 ? 2 : 1;                     // dy LDS-DMA instructions per wave and stage (8 rows each: 128 / 64 rows)
+  constexpr int DSLOT = (MP == 2 ? 128 : 64) * 128;        // a stage's dy rows of ONE row half
+  constexpr int XSLOT = CW * TZ_XRAW;                      // a stage's raw windows
+  constexpr int LO = CW * 8 * TZ_CPB, COPIES = 2 * LO;     // one copies buffer: [hi | lo][CW][8 copies][TZ_CPB]
+  constexpr int X0 = TZ_ND * DSLOT, C0 = X0 + TZ_ND * XSLOT;
+  constexpr int XU = (128 * CW) / 512;                     // x copy units per thread (1 or 2): every thread has work
   extern __shared__ __attribute__((aligned(16))) char tz_lds[];
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)tz_lds);
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave_s / TZ_CW, wk = wave_s % TZ_CW;       // row pair, channel of the group
+  const int wm = wave_s / CW, wk = wave_s % CW;            // row pair, channel of the group
   const int g = blockIdx.y, L = p.L;
-  constexpr int dslot_bytes = WW_MROWS * 128;
-  char* const xraw = tz_lds + WW_ND * dslot_bytes;          // [2 slots][TZ_CW][TZ_XRAW]
-  char* const copies = xraw + 2 * TZ_CW * TZ_XRAW;          // [hi | lo][TZ_CW][8 copies][TZ_CPB]
   const char* const zero16 = reinterpret_cast<const char*>(ww_zero16);
 
-  // ---- dy rows of this row half: ⌈M_here/8⌉ LDS-DMA instructions per stage (8 rows each), instruction i = wave + 8k
+  // ---- LDS-DMA sources.  dy: instruction i = wave + 8k fills LDS rows 8i .. 8i+7 of the slot (lane → row, piece: ww_dma_row)
   const int m_base = blockIdx.z * 128;
   const int M_here = p.m_halves > 1 ? min(128, p.M - m_base) : p.M;
-  const int nd = (M_here + 7) >> 3;
-  const int my_nd = nd > wave_s ? (nd - wave_s + 7) >> 3 : 0;
-  WwSrc dsrc[4];
+  const float* dsrc[NDW];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = wave_s + 8 * k;
-    const int r = ww_dma_row(i, lane), q = (lane ^ r) & 7;
-    dsrc[k].p = r < M_here ? p.dy + ((long long)(m_base + r) * L + 4 * q) : nullptr;
-    dsrc[k].bs = 0; dsrc[k].t = 4 * q;
+  for (int k = 0; k < NDW; ++k) {
+    const int r = ww_dma_row(wave_s + 8 * k, lane), q = (lane ^ r) & 7;
+    dsrc[k] = p.dy + ((long long)(m_base + (r < M_here ? r : 0)) * L + 4 * q);
   }
-  // ---- the window of channel CW·g + wave (waves < CW): piece `lane` (< 40) of the 160 samples from t0 − P4
-  const int my_ch = TZ_CW * g + wave_s;
-  const float* const xrow = (wave_s < TZ_CW && my_ch < p.C && lane < 40) ? p.x + ((long long)my_ch * L + 4 * lane) : nullptr;
+  // the window of channel CW·g + wave (waves < CW): piece `lane` (< 40) of the 160 samples from t0 − P4
+  const bool has_x = wave_s < CW;                          // wave-uniform
+  const int my_ch = CW * g + wave_s;
+  const bool x_lane = has_x && my_ch < p.C && lane < 40;
+  const float* const xrow = p.x + ((long long)(x_lane ? my_ch : 0) * L + 4 * lane - p.P4);
+  const int xt = 4 * lane - p.P4;                          // the piece's first sample relative to t0
   const long long dy_bs = (long long)p.M * L, x_bs = (long long)p.C * L;
   __builtin_amdgcn_s_waitcnt(0x0F70);                      // (see wn_wgrad_kernel: per-lane selections of kernel arguments)
 
-  auto tile_bt = [&](int tile, int& b, int& t0) {
-    b = tile / p.tiles_per_seq;
-    t0 = (tile - b * p.tiles_per_seq) * WW_TT;
+  // stage position: batch element and first sample as running offsets into dy / x (advanced by additions)
+  struct Pos { int t0; long long doff, xoff; };
+  auto advance = [&](Pos& q) {
+    q.t0 += WW_TT; q.doff += WW_TT; q.xoff += WW_TT;
+    if (q.t0 == L) { q.t0 = 0; q.doff += dy_bs - L; q.xoff += x_bs - L; }
   };
-  auto issue_dy1 = [&](int k, int b, int t0, int slot) {
-    if (k >= my_nd || (p.exp & 4)) return;                 // wave-uniform
-    const bool ok = dsrc[k].p != nullptr;
-    const char* src = ok ? reinterpret_cast<const char*>(dsrc[k].p + (b * dy_bs + t0)) : zero16;
-    ww_dma16(src, tz_lds + slot * dslot_bytes + (wave_s + 8 * k) * 1024);
+  auto issue_stage = [&](const Pos& q, int slot) {         // NDW dy pieces, then (waves < CW) the window piece
+    if (TZ_EXP & 4) return;
+#pragma unroll
+    for (int k = 0; k < NDW; ++k)
+      tz_dma16(reinterpret_cast<const char*>(dsrc[k] + q.doff), lds0 + slot * DSLOT + (wave_s + 8 * k) * 1024);
+    if (has_x) {
+      const int t = q.t0 + xt;                             // (multiples of 4: a piece is inside the sequence or outside it)
+      const char* src = (x_lane && t >= 0 && t < L) ? reinterpret_cast<const char*>(xrow + q.xoff) : zero16;
+      tz_dma16(src, lds0 + X0 + slot * XSLOT + wave_s * TZ_XRAW);
+    }
   };
-  auto issue_x1 = [&](int b, int t0, int slot) {
-    if (wave_s >= TZ_CW || (p.exp & 4)) return;            // wave-uniform
-    const int t = t0 - p.P4 + 4 * lane;                    // (multiples of 4: a piece is inside the sequence or outside it)
-    const bool ok = xrow != nullptr && t >= 0 && t < L;
-    const char* src = ok ? reinterpret_cast<const char*>(xrow + (b * x_bs + t0 - p.P4)) : zero16;
-    ww_dma16(src, xraw + (slot * TZ_CW + wave_s) * TZ_XRAW);
+  auto wait_keep_one = [&]() {                             // all but the youngest stage's pieces of this wave have landed
+    if (TZ_EXP & 4) return;
+    if (has_x) tz_wait_at_most<NDW + 1>(); else tz_wait_at_most<NDW>();
   };
 
   f32x16 acc[2][3];
@@ -897,156 +967,191 @@ __global__ __launch_bounds__(512, 2) void tz_wgrad_kernel(TzParams p) {
   const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.n_tiles) / p.ksplit);
   const int m_blocks = (M_here + 31) >> 5;
   const int k_blocks = (p.K + 31) >> 5;                    // live 32-shift blocks (<= 3)
-  const bool ch_live = TZ_CW * g + wk < p.C;
+  const bool ch_live = CW * g + wk < p.C;
 
-  // A fragments: as in wn_wgrad_kernel (row block·32 + l31, unit 2·ks + half: hi = first piece, lo = second)
-  const int row_l = (l31 ^ ((l31 >> 3) & 1)) << 7;
-  const int sw = l31 & 7;
-  int pc[2][2];
+  // ---- per-lane LDS offsets.  A fragments as in wn_wgrad_kernel: row block·32 + l31 (LDS row l31 ^ ((l31 >> 3) & 1)), unit
+  // 2·ks + half: hi = first piece, lo = second; the block index and the slot are immediates / one scalar
+  const int row_l = (l31 ^ ((l31 >> 3) & 1)) << 7, sw = l31 & 7;
+  unsigned a_lane[2][2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    pc[ks][0] = (((4 * ks + 2 * half) ^ sw) & 7) << 4;
-    pc[ks][1] = (((4 * ks + 2 * half + 1) ^ sw) & 7) << 4;
-  }
-  const int a_off = ((wm * 2 * 32) << 7) + row_l;
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a_lane[ks][j] = ((wm * 2 * 32) << 7) + row_l + ((((4 * ks + 2 * half + j) ^ sw) & 7) << 4);
   // B fragments: shift s = 32·sb + l31 at samples 16·ks + 8·half + 0..7 → window offset o = off0 + s + 16·ks + 8·half: copy o & 7
   // (the same for every ks, sb), unit o >> 3
   const int o0 = p.off0 + l31 + 8 * half;
-  const int b_off = wk * (8 * TZ_CPB) + (o0 & 7) * TZ_CPB + ((o0 >> 3) << 4);
+  const unsigned b_lane = wk * (8 * TZ_CPB) + (o0 & 7) * TZ_CPB + ((o0 >> 3) << 4);
+  // split pass.  dy: thread t owns unit t & 3 (8 samples) of row t >> 2: pieces 2u, 2u + 1 (MP = 1: the slot has 64 rows, waves
+  // 0-3 only).  x: unit id = t + 512j → channel id >> 7, copy (id >> 4) & 7, 16-byte unit id & 15: window samples 8q + r .. + 7
+  const int su = tid & 3, sr = tid >> 2;
+  const bool dy_thread = MP == 2 || wave_s < 4;            // wave-uniform
+  const unsigned sd_lane0 = ww_lds_off(sr, 2 * su), sd_lane1 = ww_lds_off(sr, 2 * su + 1);
+  unsigned sx_src[XU], sx_dst[XU];
+#pragma unroll
+  for (int j = 0; j < XU; ++j) {
+    const int id = tid + 512 * j, xc = id >> 7, xr = (id >> 4) & 7, xq = id & 15;
+    sx_src[j] = xc * TZ_XRAW + (8 * xq + xr) * 4;
+    sx_dst[j] = xc * (8 * TZ_CPB) + xr * TZ_CPB + (xq << 4);
+  }
 
-  const int n_st = tile_end - tile_begin;
+  // Software pipeline over stages: while stage c multiplies, stage c + 1 — landed in its ring slot during stage c − 1 — goes through
+  // the split pass (dy rows in place, the x windows into the OTHER copies buffer) and the pieces of stage c + 3 are issued, in chunks
+  // between the MFMA groups.  One barrier per stage.
+  const int n_st = (TZ_EXP & 32) ? 0 : tile_end - tile_begin;
+  ww_f32x4 sd0, sd1;
+  float sxv[XU][8];
+  auto split_load = [&](unsigned d_slot, unsigned x_slot) {
+    if (TZ_EXP & 2) return;
+    if (dy_thread) { sd0 = tz_read16<0>(d_slot + sd_lane0); sd1 = tz_read16<0>(d_slot + sd_lane1); }
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+      const unsigned a = x_slot + sx_src[j];
+      sxv[j][0] = tz_read4<0>(a); sxv[j][1] = tz_read4<4>(a); sxv[j][2] = tz_read4<8>(a); sxv[j][3] = tz_read4<12>(a);
+      sxv[j][4] = tz_read4<16>(a); sxv[j][5] = tz_read4<20>(a); sxv[j][6] = tz_read4<24>(a); sxv[j][7] = tz_read4<28>(a);
+    }
+  };
+  auto split_dy_store = [&](unsigned d_slot) {
+    if ((TZ_EXP & 2) || !dy_thread) return;
+    ww_u32x4 h4, l4;
+    ww_split8u(sd0, sd1, h4, l4);
+    tz_write16<0>(d_slot + sd_lane0, h4); tz_write16<0>(d_slot + sd_lane1, l4);
+  };
+  auto split_x_store = [&](unsigned cbuf) {
+    if (TZ_EXP & 2) return;
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+      ww_u32x4 h4, l4;
+      unsigned hh, ll;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ww_split_pair(sxv[j][2 * e], sxv[j][2 * e + 1], hh, ll); h4[e] = hh; l4[e] = ll; }
+      tz_write16<0>(cbuf + sx_dst[j], h4);
+      tz_write16<LO>(cbuf + sx_dst[j], l4);
+    }
+  };
+
+  Pos pos;                                                 // position of the stage issued next
   {
-    int b, t0;
-    if (n_st > 0) {
-      tile_bt(tile_begin, b, t0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) issue_dy1(k, b, t0, 0);
-      issue_x1(b, t0, 0);
-    }
-    if (n_st > 1) {
-      tile_bt(tile_begin + 1, b, t0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) issue_dy1(k, b, t0, 1);
-    }
+    const int b = tile_begin / p.tiles_per_seq;
+    pos.t0 = (tile_begin - b * p.tiles_per_seq) * WW_TT;
+    pos.doff = (long long)b * dy_bs + pos.t0;
+    pos.xoff = (long long)b * x_bs + pos.t0;
   }
-  int dslot = 0, xslot = 0;
+  int issued = 0;                                          // stages issued so far; past n_st the last one is issued again ("virtual")
+  auto issue_next = [&](int slot) {
+    issue_stage(pos, slot);
+    ++issued;
+    if (issued < n_st) advance(pos);
+  };
+  // ONE barrier per stage, in its middle, and no burst of LDS reads behind it: the fragments of k-step 0 of stage c + 1 are read
+  // right after that barrier, under the MFMAs of k-step 1 of stage c; those of k-step 1 at the top of the stage, under the MFMAs of
+  // k-step 0.  (Stamps of the form with the barrier at the top: the issue of the 20 LDS reads behind it took 20 % of a wave's stage —
+  // all eight waves read at once and nobody could multiply yet — the barrier 13 %, profiles/r04_tz_stamps.txt.)
+  ww_f32x4 araw[2][2][2], braw[2][3][2];
+  auto frag_reads = [&](auto ks_c, unsigned d_slot, unsigned cbuf) {
+    constexpr int ks = decltype(ks_c)::value;
+    if (TZ_EXP & 8) return;
+    araw[ks][0][0] = tz_read16<0>(d_slot + a_lane[ks][0]);    araw[ks][0][1] = tz_read16<0>(d_slot + a_lane[ks][1]);
+    araw[ks][1][0] = tz_read16<4096>(d_slot + a_lane[ks][0]); araw[ks][1][1] = tz_read16<4096>(d_slot + a_lane[ks][1]);
+    const unsigned bb = cbuf + b_lane;
+    braw[ks][0][0] = tz_read16<((2 * ks) << 4)>(bb);      braw[ks][0][1] = tz_read16<((2 * ks) << 4) + LO>(bb);
+    braw[ks][1][0] = tz_read16<((2 * ks + 4) << 4)>(bb);  braw[ks][1][1] = tz_read16<((2 * ks + 4) << 4) + LO>(bb);
+    braw[ks][2][0] = tz_read16<((2 * ks + 8) << 4)>(bb);  braw[ks][2][1] = tz_read16<((2 * ks + 8) << 4) + LO>(bb);
+  };
+  auto mfma_group = [&](int ks, int sb) {
+    if (!(TZ_EXP & 1) && (FULL || (sb < k_blocks && ch_live))) {       // wave-uniform
+      const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[ks][sb][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[ks][sb][1]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!FULL && wm * 2 + i >= m_blocks) break;        // wave-uniform
+        const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[ks][i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[ks][i][1]);
+        acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][sb], 0, 0, 0);
+        acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][sb], 0, 0, 0);
+        acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][sb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  TZ_SUMS;
+  TZ_T(tz_begin);
+  if (n_st > 0) {
+    issue_next(0);
+    issue_next(1);
+    wait_keep_one();                                       // stage 0 has landed
+    __builtin_amdgcn_s_barrier();
+    split_load(lds0, lds0 + X0);                           // stage 0 has nothing to hide under
+    ww_lds_wait();
+    split_dy_store(lds0); split_x_store(lds0 + C0);
+    issue_next(2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_keep_one();                                       // stage 1 has landed
+    __builtin_amdgcn_s_barrier();                          // split(0) of every wave is visible
+    frag_reads(std::integral_constant<int, 0>{}, lds0, lds0 + C0);
+  }
+  int slot = 0, cb = 0;                                    // ring slot of stage c
   for (int c = 0; c < n_st; ++c) {
-    // everything but the dy pieces of stage c + 1 (this wave's my_nd most recent issues) has landed
-    if (c + 1 >= n_st || my_nd == 0) tz_wait_at_most<0>();
-    else if (my_nd == 1) tz_wait_at_most<1>();
-    else if (my_nd == 2) tz_wait_at_most<2>();
-    else if (my_nd == 3) tz_wait_at_most<3>();
-    else tz_wait_at_most<4>();
-    __builtin_amdgcn_s_barrier();
-    const bool have_x = c + 1 < n_st, have_dy = c + 2 < n_st;
-    int nb = 0, nt0 = 0, db = 0, dt0 = 0;
-    if (have_x) tile_bt(tile_begin + c + 1, nb, nt0);
-    if (have_dy) tile_bt(tile_begin + c + 2, db, dt0);
-    const int x_next = xslot ^ 1, d_next = dslot >= 1 ? dslot - 1 : 2;
-    auto issue_pos = [&](int pos) {                        // pos 0: the window piece; 1..4: dy pieces (issue order as counted above)
-      if (pos == 0) { if (have_x) issue_x1(nb, nt0, x_next); }
-      else if (pos <= 4) { if (have_dy) issue_dy1(pos - 1, db, dt0, d_next); }
-    };
-    // ---- split pass.  dy: in place (thread t: units t and t + 512 = rows t>>2 and 128 + (t>>2), unit t&3).  x: thread t < 256 builds
-    // unit q = t & 15 of copy r = (t >> 4) & 7 of channel t >> 7: window samples 8q + r .. 8q + r + 7
-    if (!(p.exp & 2)) {
-      char* const dw = tz_lds + dslot * dslot_bytes;
-      const int u = tid & 3, r0 = tid >> 2;
-      ww_f32x4 d[2][2];
-      char* da[2][2];
-      const int dy_rows = nd << 3;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = r0 + 128 * i;
-        da[i][0] = dw + ww_lds_off(r, 2 * u); da[i][1] = dw + ww_lds_off(r, 2 * u + 1);
-        if (r < dy_rows) { d[i][0] = ww_lds_read16(da[i][0]); d[i][1] = ww_lds_read16(da[i][1]); }
-      }
-      constexpr int XU = (128 * TZ_CW + 511) / 512;         // copy units per thread (unit id = tid + 512·j)
-      float xv[XU][8];
-#pragma unroll
-      for (int j = 0; j < XU; ++j) {
-        const int id = tid + 512 * j;
-        if (id < 128 * TZ_CW) {
-          const int xc = id >> 7, xr = (id >> 4) & 7, xq = id & 15;
-          const char* src = xraw + (xslot * TZ_CW + xc) * TZ_XRAW + (8 * xq + xr) * 4;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) xv[j][e] = tz_lds_read4(src + 4 * e);
-        }
-      }
-      ww_lds_wait();
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = r0 + 128 * i;
-        if (r < dy_rows) {
-          ww_u32x4 h4, l4;
-          ww_split8u(d[i][0], d[i][1], h4, l4);
-          ww_lds_write16(da[i][0], h4); ww_lds_write16(da[i][1], l4);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < XU; ++j) {
-        const int id = tid + 512 * j;
-        if (id < 128 * TZ_CW) {
-          const int xc = id >> 7, xr = (id >> 4) & 7, xq = id & 15;
-          ww_u32x4 h4, l4;
-          unsigned hh, ll;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { ww_split_pair(xv[j][2 * e], xv[j][2 * e + 1], hh, ll); h4[e] = hh; l4[e] = ll; }
-          char* dst = copies + xc * (8 * TZ_CPB) + xr * TZ_CPB + (xq << 4);
-          ww_lds_write16(dst, h4);
-          ww_lds_write16(dst + TZ_CW * 8 * TZ_CPB, l4);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    // ---- multiply
-    const char* const dsl = tz_lds + dslot * dslot_bytes;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      ww_f32x4 araw[2][2], braw[3][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const char* ap = dsl + a_off + ((i * 32) << 7);
-        araw[i][0] = ww_lds_read16(ap + pc[ks][0]);
-        araw[i][1] = ww_lds_read16(ap + pc[ks][1]);
-      }
-#pragma unroll
-      for (int sb = 0; sb < 3; ++sb) {
-        const char* bp = copies + b_off + ((2 * ks + 4 * sb) << 4);
-        braw[sb][0] = ww_lds_read16(bp);
-        braw[sb][1] = ww_lds_read16(bp + TZ_CW * 8 * TZ_CPB);
-      }
-      ww_lds_wait();
-      issue_pos(3 * ks);
-#pragma unroll
-      for (int sb = 0; sb < 3; ++sb) {
-        if (sb < k_blocks && ch_live && !(p.exp & 1)) {    // wave-uniform
-          const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[sb][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[sb][1]);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            if (wm * 2 + i >= m_blocks) break;             // wave-uniform
-            const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[i][1]);
-            acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][sb], 0, 0, 0);
-            acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][sb], 0, 0, 0);
-            acc[i][sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][sb], 0, 0, 0);
-          }
-        }
-        if (ks == 0) { if (sb < 2) issue_pos(1 + sb); }    // pos 0 | 1 2 | 3 | 4 5(none)
-        else if (sb == 0) issue_pos(4);
-      }
-    }
-    dslot = dslot == WW_ND - 1 ? 0 : dslot + 1;
-    xslot ^= 1;
+    const int s_next = (slot + 1) & (TZ_ND - 1), s_dma = (slot + 3) & (TZ_ND - 1);   // c + 3 goes where multiply(c − 1) read
+    const unsigned d_cur = lds0 + slot * DSLOT, d_nxt = lds0 + s_next * DSLOT, x_nxt = lds0 + X0 + s_next * XSLOT;
+    const unsigned c_cur = lds0 + C0 + cb * COPIES, c_nxt = lds0 + C0 + (cb ^ 1) * COPIES;
+    TZ_T(ta);
+    ww_lds_wait();                                         // the k-step-0 fragments (read under the previous stage's last MFMAs)
+    TZ_T(tb);
+    TZ_ACC(0, ta, tb);                                     // wait for the k-step-0 fragments
+    frag_reads(std::integral_constant<int, 1>{}, d_cur, c_cur);
+    split_load(d_nxt, x_nxt);                              // stage c + 1 landed before the previous barrier (virtual past the end)
+    TZ_T(tc);
+    TZ_ACC(2, tb, tc);                                     // issue of the k-step-1 fragment reads + split reads
+    mfma_group(0, 0);
+    TZ_T(td);
+    TZ_ACC(4, tc, td);                                     // MFMA group (0, 0)
+    ww_lds_wait();
+    TZ_T(te);
+    TZ_ACC(3, td, te);                                     // wait for those reads
+    split_dy_store(d_nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    TZ_T(tf);
+    TZ_ACC(5, te, tf);                                     // dy split
+    mfma_group(0, 1);
+    TZ_T(tg);
+    TZ_ACC(4, tf, tg);
+    split_x_store(c_nxt);                                  // (its stores complete under the group below)
+    __builtin_amdgcn_sched_barrier(0);
+    TZ_T(th);
+    TZ_ACC(7, tg, th);                                     // x split
+    mfma_group(0, 2);
+    TZ_T(ti);
+    TZ_ACC(4, th, ti);
+    issue_next(s_dma);                                     // this wave's pieces of stage c + 3
+    TZ_T(tj);
+    TZ_ACC(6, ti, tj);                                     // LDS-DMA issue
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's split stores of stage c + 1 are done ...
+    wait_keep_one();                                       // ... and its pieces of stage c + 2 have landed (c + 3 may still fly)
+    TZ_T(tk);
+    TZ_ACC(8, tj, tk);                                     // waits in front of the barrier
+    __builtin_amdgcn_s_barrier();                          // split(c + 1) is visible; everyone is past its reads of stage c
+    TZ_T(tl);
+    TZ_ACC(1, tk, tl);                                     // barrier
+    frag_reads(std::integral_constant<int, 0>{}, d_nxt, c_nxt);     // k-step 0 of stage c + 1, under the MFMAs below
+    mfma_group(1, 0);
+    mfma_group(1, 1);
+    mfma_group(1, 2);
+    TZ_T(tm);
+    TZ_ACC(9, tl, tm);                                     // fragment reads of the next stage + MFMA groups of k-step 1
+    slot = s_next;
+    cb ^= 1;
   }
+  TZ_T(tz_end);
+  TZ_ACC(10, tz_begin, tz_end);                            // whole loop
+  TZ_FLUSH;
+  // (virtual pieces may still be in flight: they target LDS only, and the wave's end waits for them)
 
   float* const slab = p.slab + (long long)blockIdx.x * WW_MROWS * p.Kcols;
+  if (TZ_EXP & 16) return;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (wm * 2 + i >= m_blocks) break;
 #pragma unroll
     for (int sb = 0; sb < 3; ++sb) {
-      float* dst = slab + (long long)(m_base + (wm * 2 + i) * 32 + 4 * half) * p.Kcols + g * (TZ_CW * 96) + wk * 96 + sb * 32 + l31;
+      float* dst = slab + (long long)(m_base + (wm * 2 + i) * 32 + 4 * half) * p.Kcols + g * (CW * 96) + wk * 96 + sb * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[(long long)((r & 3) + 8 * (r >> 2)) * p.Kcols] = acc[i][sb][r];
     }
@@ -1112,11 +1217,13 @@ extern "C" int fst_dense_tap_wgrad(const float* dy, const float* x, float* dw, f
   FST_REQUIRE(workspace_floats >= (int64_t)p.ksplit * WW_MROWS * p.Kcols, "fst_dense_tap_wgrad: workspace of %lld floats is too small",
               (long long)workspace_floats);
   p.dy = dy; p.x = x; p.dw = dw; p.slab = workspace;
-  static const int exp_env = getenv("FST_TZ_EXP") ? atoi(getenv("FST_TZ_EXP")) : 0;
-  p.exp = exp_env;
   const int cw = 8 / MP;
-  const size_t lds = (size_t)WW_ND * WW_MROWS * 128 + 2 * cw * TZ_XRAW + (size_t)cw * 2 * 8 * TZ_CPB;
-  void (*fn)(TzParams) = MP == 1 ? tz_wgrad_kernel<1> : tz_wgrad_kernel<2>;
+  const size_t lds = (size_t)TZ_ND * (MP == 1 ? 64 : 128) * 128 + TZ_ND * cw * TZ_XRAW + 2 * (size_t)cw * 2 * 8 * TZ_CPB;   // dy ring, window ring, two copies buffers
+  // FULL: every 32-row block of every row half and all three 32-shift blocks are live: no block tests around the MFMAs
+  const int rows_block = MP == 2 ? 128 : 64, last_half = M - (p.m_halves - 1) * 128;
+  const bool full = K > 64 && (p.m_halves > 1 ? last_half > 96 : M > rows_block - 32);
+  void (*fn)(TzParams) = MP == 1 ? (full ? tz_wgrad_kernel<1, true> : tz_wgrad_kernel<1, false>)
+                                 : (full ? tz_wgrad_kernel<2, true> : tz_wgrad_kernel<2, false>);
   if (int rc = fst_allow_full_lds((const void*)fn, "fst_dense_tap_wgrad")) return rc;
   hipLaunchKernelGGL(fn, dim3((unsigned)p.ksplit, (unsigned)p.n_groups, (unsigned)p.m_halves), dim3(512), lds, (hipStream_t)stream, p);
   FST_LAUNCH_CHECK();
