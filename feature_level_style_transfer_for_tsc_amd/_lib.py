@@ -56,6 +56,8 @@ _SIGNATURES = {
     "fst_coupling_inv_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_rmsprop_multi": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, c_float, c_void_p]),
     "fst_adam_multi": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_float, c_float, c_float, c_float, c_void_p]),
+    "fst_wn_stack_fwd_ok": (c_int, [c_int, c_int, c_int, c_int]),
+    "fst_wn_stack_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_stack_bwd_ok": (c_int, [c_int, c_int, c_int, c_int]),
     "fst_wn_stack_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_void_p]),
     "fst_wn_wgrad_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -35,6 +35,7 @@ typedef unsigned wn_u32x4 __attribute__((ext_vector_type(4)));
 #define WN_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define WN_LDS_VOID(p) ((__attribute__((address_space(3))) void*)(p))
 
+#define WS_MAXL 10                                  // layers of a WN stack the one-launch kernels take (tables in the kernel arguments)
 #define WN_TN 128                                  // time samples per workgroup
 // forward kernel, per NW waves: WN_NBLK = NW + 1 32-sample column blocks per 8-channel row group (+1: sub-shift spill), WN_GS =
 // WN_NBLK·1024 + 128 bytes per row group (+128: the lane halves hit different banks), ring slot = WN_A_BYTES + 2·WN_GS
@@ -321,6 +322,69 @@ __device__ __forceinline__ void wn_tile_to_acc(float (&v)[16], const float4 (&q)
   for (int r = 0; r < 16; ++r) v[r] = tile[((r & 3) + 8 * (r >> 2) + 4 * half) * 36 + l31];
 }
 
+// Accumulator layout <-> global memory through raw buffer instructions: one descriptor per [rows][L] matrix of a batch element,
+// ONE per-lane byte offset for the whole kernel (vlane = (4·half·L + l31)·4) and the row / column term of every access in the
+// instruction's scalar offset — an access is one buffer_load/store_dword with no VALU work, no 64-bit address and no exec mask
+// (wn_acc_load / _store form sixteen per-lane addresses per tile; the persistent kernel below has no registers for that).
+// Columns beyond the sequence: the lane's offset is pushed out of the descriptor's range (loads return 0, stores are dropped by
+// the hardware's range check).  Rows beyond the matrix: wave-uniform tests per register (the two lane halves of a register
+// are 4 rows apart: a register whose upper half only is out of range goes through the half-masked offset).
+#define WS_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x40000000, 0x00020000);
+}
+struct WsLane { unsigned vo, vo_lo; };     // offsets of a lane whose column exists: both halves / lower half only
+__device__ __forceinline__ WsLane ws_lane(unsigned vlane, int tcol, int L, int lane) {
+  WsLane w;
+  w.vo = tcol + (lane & 31) < L ? vlane : WS_OOB;
+  w.vo_lo = lane < 32 ? w.vo : WS_OOB;
+  return w;
+}
+// tile = rows row0 .. row0+31 (rv of them exist, rv may be <= 0 or >= 32), columns tcol .. tcol+31 of the matrix behind `rs`
+// (The scalar offsets are formed from an opaque copy of L: loop-invariant otherwise, the compiler computes those of every tile of
+// the kernel ahead of the layer loop and keeps — i.e. spills — hundreds of them.)
+__device__ __forceinline__ int ws_opaque(int x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+template <int AUX = 0>
+__device__ __forceinline__ void ws_acc_load(f32x16& v, __amdgpu_buffer_rsrc_t rs, const WsLane w, int row0, int tcol, int rv, int L) {
+  L = ws_opaque(L);
+  rv = ws_opaque(rv);
+  const int sbase = (row0 * L + tcol) * 4;
+  if (rv >= 32) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, AUX));
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      float x = 0.f;
+      if (row < rv) x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, AUX));
+      v[r] = x;
+    }
+  }
+}
+template <int AUX = 0, class V>
+__device__ __forceinline__ void ws_acc_store(const V& v, __amdgpu_buffer_rsrc_t rs, const WsLane w, int row0, int tcol, int rv, int L) {
+  L = ws_opaque(L);
+  rv = ws_opaque(rv);
+  const int sbase = (row0 * L + tcol) * 4;
+  if (rv >= 32) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, AUX);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2);
+      if (row < rv)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, AUX);
+    }
+  }
+}
+
 // Row sums of an accumulator tile on its way out (bias gradients: Σ_{b,t} of every row): after the transpose each lane
 // holds four consecutive samples of rows rrow + 8j, so a row's 32 samples are 8 lanes × float4 — three butterfly steps,
 // then one LDS float add per row and wave.  `rows` = this WAVE's LDS array indexed by the tile's absolute row: one lane owns
@@ -343,23 +407,20 @@ __device__ __forceinline__ void wn_tile_row_sums(const float* tile, float* rows,
 // NW waves per workgroup = 32·NW time samples: every wave streams the whole weight image through LDS whatever the tile width, so
 // the L2→LDS fill per sample — the limiter of the 4-wave form (830 MB of pieces per launch) — halves at NW = 8
 // (one workgroup of 8 waves per CU instead of two of 4: the same 2 waves per SIMD).
+// one tile (32·NW samples from t0 of batch element b) of one layer: the whole body of the forward kernel
+// (the arguments stay in the kernel-argument segment — constant address space: scalar loads at the point of use, rematerialised
+// rather than kept in registers — for the per-layer kernel and for the persistent one alike)
+typedef const __attribute__((address_space(4))) WnFwdParams WnFwdArgs;
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(WnFwdParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void wn_fwd_tile(WnFwdArgs& p, const int b, const int t0, char* const ldsb) {
   constexpr int F_TN = 32 * NW, F_NBLK = F_TN / 32 + 1, F_GS = F_NBLK * 1024 + 128, F_SLOT = WN_A_BYTES + 2 * F_GS;
   constexpr int NA = WN_A_BYTES / 1024;              // 16 one-KiB pieces of A per stage
   constexpr int NI1 = NA + 2 * F_NBLK;              // 26 (NW = 4) / 34 (NW = 8) LDS-DMA wave-instructions per GEMM-1 stage
-  char* const ldsb = reinterpret_cast<char*>(lds);
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid_o = threadIdx.x;
+  asm volatile("" : "+v"(tid_o));                    // opaque per call: in the persistent kernel nothing derived from the lane id is
+  const int tid = tid_o, lane = tid & 63;            //   hoisted out of the tile loops and kept alive across the whole body
   const int half = lane >> 5, l31 = lane & 31;
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // Workgroup → tile: ids that differ by a multiple of 8 share an XCD (round-robin dispatch), so give each XCD a
-  // contiguous run of tiles: the tiles of one sequence, which re-read each other's halo for the dilated taps, then
-  // meet in one L2.  Speed only.
-  int wg = blockIdx.x;
-  if ((p.n_wg & 7) == 0) wg = (wg & 7) * (p.n_wg >> 3) + (wg >> 3);
-  const int b = wg / p.tiles_per_seq;
-  const int t0 = (wg - b * p.tiles_per_seq) * F_TN;
   const int wave_n0 = wave_s * 32;
   const int L = p.L, n = p.n, h = p.h, CH = p.CH;
   const int S1 = 3 * CH + p.CH2;
@@ -489,9 +550,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
     const char* base = ldsb + slot * F_SLOT;
     const int colx = wave_n0 + l31 + sub;
     const char* bp = base + WN_A_BYTES + half * F_GS + (colx >> 5) * 1024 + (colx & 31) * 4;
+    // A fragments run ONE row block ahead of the MFMAs that consume them (two register pairs in rotation): read right in front
+    // of their MFMAs — as the first form of this loop did, one `ds_read_b128; s_waitcnt lgkmcnt(0)` per fragment — every one of the
+    // 16 reads of a stage exposed the LDS latency to a wave with nothing else to issue (115 such waits in the kernel's code)
+    wn_bf16x8 fah[2], fal[2];
+    auto a_frag = [&](int mb) {
+      fah[mb % 2] = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
+      fal[mb % 2] = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+    };
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (WN_EXP & 32) ? (float)(k + j) : *reinterpret_cast<const float*>(bp + j * 128);
+    a_frag(0);                                             // lands under the split of the B fragment below
     wn_u32x4 bh4, bl4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -508,8 +578,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
     WN_ACC(4, td, te);                                 // B fragment: LDS reads + split
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
-      const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
-      const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+      if (mb + 1 < 8) a_frag(mb + 1);
+      const wn_bf16x8 ah = fah[mb % 2], al = fal[mb % 2];
       if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh), "v"(bl)); }
       else {
         acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
@@ -538,7 +608,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
   wn_wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();                        // every wave is past its last B read: the B areas are free
   const int tcol = t0 + wave_n0;
-  float* const ts_b = p.ts + (long long)b * (2 * n) * L;
+  // accumulator-layout global accesses as raw buffer instructions: one descriptor per matrix of this batch element, ONE per-lane
+  // offset, row / column terms in the scalar offset (no 64-bit per-lane addresses, no exec masks: see ws_acc_load)
+  const WsLane wl = ws_lane((unsigned)(4 * half * L + l31) * 4u, tcol, L, lane);
+  const __amdgpu_buffer_rsrc_t ts_rs = ws_rsrc(p.ts + (long long)b * (2 * n) * L);
+  const __amdgpu_buffer_rsrc_t a_rs = ws_rsrc(ab), out_rs = ws_rsrc(p.out + (long long)b * n * L);
+  const __amdgpu_buffer_rsrc_t an_rs = ws_rsrc(p.a_next ? p.a_next + (long long)b * n * L : p.out);
   wn_bf16x8 bh2[8], bl2[8];
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
@@ -552,8 +627,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
       av[r] = row == n ? 1.0f : tv[r] * sv[r];         // acts[n] = 1 carries b_rs through GEMM 2 (rows > n: tanh(0)·σ(0) = 0)
     }
     const int rows_valid = (WN_EXP & 8) ? 0 : n - blk * 32;               // may be <= 0: nothing stored
-    wn_acc_store(tv, ts_b + (long long)(blk * 32) * L, rows_valid, L, tcol, lane);
-    wn_acc_store(sv, ts_b + (long long)(n + blk * 32) * L, rows_valid, L, tcol, lane);
+    ws_acc_store(tv, ts_rs, wl, blk * 32, tcol, rows_valid, L);
+    ws_acc_store(sv, ts_rs, wl, n + blk * 32, tcol, rows_valid, L);
     if (p.acts) {
       float aw[16];
 #pragma unroll
@@ -565,8 +640,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
     // gate has just consumed: the round trip hides under the remaining gate blocks and the first k-steps
     {
       const int rows_e = (WN_EXP & 16) ? 0 : n - blk * 32;
-      wn_acc_load(acc[blk], ab + (long long)(blk * 32) * L, p.last ? 0 : rows_e, L, tcol, lane);
-      wn_acc_load(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, ((p.first != 0) | ((WN_EXP & 64) != 0)) ? 0 : rows_e, L, tcol, lane);
+      ws_acc_load(acc[blk], a_rs, wl, blk * 32, tcol, p.last ? 0 : rows_e, L);
+      ws_acc_load(acc[blk + 4], out_rs, wl, blk * 32, tcol, ((p.first != 0) | ((WN_EXP & 64) != 0)) ? 0 : rows_e, L);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -600,11 +675,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
     }
 #endif
     const char* base = ldsb + slot * F_SLOT;
+    // (fragments one row block ahead, as in GEMM 1; on the last layer the residual-row blocks 0-3 are neither read nor multiplied)
+    wn_bf16x8 fah[2], fal[2];
+    auto a_frag = [&](int mb) {
+      fah[mb % 2] = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
+      fal[mb % 2] = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+    };
+    if (!p.last) a_frag(0);
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
+      if (mb + 1 < 8 && !(p.last && mb + 1 < 4)) a_frag(mb + 1);
       if (!(p.last && mb < 4) && !((WN_EXP & 64) && mb >= 4)) {                       // wave-uniform
-        const wn_bf16x8 ah = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + lane * 16);
-        const wn_bf16x8 al = *reinterpret_cast<const wn_bf16x8*>(base + mb * 2048 + 1024 + lane * 16);
+        const wn_bf16x8 ah = fah[mb % 2], al = fal[mb % 2];
         if (WN_EXP & 1) { asm volatile("" ::"v"(al), "v"(ah), "v"(bh2[ks]), "v"(bl2[ks])); }
         else {
           acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh2[ks], acc[mb], 0, 0, 0);
@@ -630,13 +712,110 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(
 #pragma unroll
   for (int blk = 0; blk < ((WN_EXP & 16) ? 0 : 4); ++blk) {
     const int rows_e = n - blk * 32;
-    if (!p.last) wn_acc_store(acc[blk], p.a_next + ((long long)b * n + blk * 32) * L, rows_e, L, tcol, lane);
-    if (!(WN_EXP & 64)) wn_acc_store(acc[blk + 4], p.out + ((long long)b * n + blk * 32) * L, rows_e, L, tcol, lane);
+    if (!p.last) ws_acc_store(acc[blk], an_rs, wl, blk * 32, tcol, rows_e, L);
+    if (!(WN_EXP & 64)) ws_acc_store(acc[blk + 4], out_rs, wl, blk * 32, tcol, rows_e, L);
   }
   WN_T(tg3);
   WN_ACC(8, tg2, tg3);                                 // final epilogue (issue; includes waiting for the operand loads)
   WN_ACC(9, ts0, tg3);                                 // whole wave
   WN_FLUSH;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void wn_layer_fwd_kernel(WnFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // Workgroup → tile: ids that differ by a multiple of 8 share an XCD (round-robin dispatch), so give each XCD a
+  // contiguous run of tiles: the tiles of one sequence, which re-read each other's halo for the dilated taps, then
+  // meet in one L2.  Speed only.
+  int wg = blockIdx.x;
+  if ((p.n_wg & 7) == 0) wg = (wg & 7) * (p.n_wg >> 3) + (wg >> 3);
+  const int b = wg / p.tiles_per_seq;
+  const int t0 = (wg - b * p.tiles_per_seq) * (32 * NW);
+  wn_fwd_tile<NW>(*(WnFwdArgs*)__builtin_amdgcn_kernarg_segment_ptr(), b, t0, reinterpret_cast<char*>(lds));
+}
+
+// ------------------------------------------------------------------------------------------------
+// The forward of a whole WN stack in ONE persistent launch
+//
+// Launched layer by layer, every workgroup of the forward kernel walks the same phases at the same time — operand fetch, GEMM 1,
+// the gate with its t,s stores, GEMM 2, the a_next / out stores — and the memory system alternates between idle (the GEMMs) and
+// saturated (245 MB of stores + 195 MB of loads per layer in two bursts per tile round: the epilogue alone is 126 MB that no
+// CU can multiply under; stamps: a third of a wave's life, profiles/r03_wn_fwd_stamps.txt).  Here ONE workgroup walks all tiles
+// of its batch elements through all layers (the same tile body, the layer's arguments from tables in the kernel-argument
+// segment; a_next / out of one layer are read by the next through the SAME CU: s_waitcnt vmcnt(0) + barrier between tiles, as in
+// wn_stack_bwd_kernel), nothing synchronises the workgroups with each other, and `stagger` starts every other workgroup half a
+// tile late: one half of the chip stores while the other multiplies.
+// ------------------------------------------------------------------------------------------------
+struct WnFwdStackParams {
+  WnFwdParams layer[WS_MAXL];      // every layer's arguments as the per-layer launch would get them (a = the previous layer's a_next)
+  int nl, stagger;
+};
+
+__global__ __launch_bounds__(512, 1) void wn_stack_fwd_kernel(WnFwdStackParams ps_by_value) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // a layer's arguments are read where they are used, with scalar loads from the kernel-argument segment at a run-time offset
+  // (invariant memory: nothing has to stay in registers across the tile body)
+  typedef const __attribute__((address_space(4))) WnFwdStackParams StackArgs;
+  StackArgs& ps = *(StackArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)ps_by_value;
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  if ((blockIdx.x >> 3) & 1)                                // workgroup ids 8 apart share an XCD: alternate WITHIN each XCD
+    for (int i = 0; i < ps.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  const int B = ps.layer[0].B, passes = ps.layer[0].tiles_per_seq;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    for (int layer = 0; layer < ps.nl; ++layer) {
+      for (int pass = 0; pass < passes; ++pass) {
+        WnFwdArgs* qp = &ps.layer[layer];
+        asm volatile("" : "+s"(qp));                       // (opaque: the layer's arguments are loaded inside the tile body, not hoisted out of the loops)
+        wn_fwd_tile<8>(*qp, b, pass * 256, ldsb);
+        // this tile's stores (a_next, out, t,s) are complete and every wave is past its LDS reads before the next tile's
+        // LDS-DMA refills the ring and reads what was stored
+        wn_wait_vmcnt<0>();
+        __syncthreads();
+      }
+    }
+  }
+}
+
+extern "C" int fst_wn_stack_fwd_ok(int n, int h, int L, int nl) {
+  return n > 0 && n < 128 && h > 0 && L > 0 && L % 256 == 0 && nl >= 1 && nl <= WS_MAXL;
+}
+
+extern "C" int fst_wn_stack_fwd(const float* const* a_in, const int64_t* a_bs, const void* const* images, int64_t image_bytes,
+                                float* const* ts, float* const* a_next, const float* u0, int64_t u0_bs, float* out, int nl, int B,
+                                int L, int n, int h, int64_t numel_a, void* stream) {
+  FST_REQUIRE(a_in && a_bs && images && ts && a_next && u0 && out, "fst_wn_stack_fwd: null operand");
+  FST_REQUIRE(fst_wn_stack_fwd_ok(n, h, L, nl) && B > 0, "fst_wn_stack_fwd: B=%d L=%d n=%d h=%d nl=%d (needs n < 128, L %% 256 == 0, "
+              "1 <= nl <= %d)", B, L, n, h, nl, WS_MAXL);
+  FST_REQUIRE((long long)B * n * L == (long long)numel_a, "fst_wn_stack_fwd: B*n*L = %d*%d*%d does not match the element count %lld "
+              "of the [B, n, L] tensors", B, n, L, (long long)numel_a);
+  FST_REQUIRE(image_bytes == fst_wn_image_bytes(n, h), "fst_wn_stack_fwd: images are %lld bytes, expected %lld",
+              (long long)image_bytes, (long long)fst_wn_image_bytes(n, h));
+  FST_REQUIRE(B == 1 || u0_bs >= (int64_t)h * L, "fst_wn_stack_fwd: batch stride of u0 smaller than a sample");
+  auto al16 = [](const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  FST_REQUIRE(u0_bs % 4 == 0 && al16(u0) && al16(out), "fst_wn_stack_fwd: needs 16-byte aligned tensors");
+  WnFwdStackParams p = {};
+  for (int i = 0; i < nl; ++i) {
+    FST_REQUIRE(a_in[i] && images[i] && ts[i] && (a_next[i] || i == nl - 1), "fst_wn_stack_fwd: null operand of layer %d", i);
+    FST_REQUIRE(a_bs[i] >= (int64_t)n * L && a_bs[i] % 4 == 0 && al16(a_in[i]) && al16(images[i]) && al16(ts[i]) && al16(a_next[i]),
+                "fst_wn_stack_fwd: layer %d: batch stride %lld smaller than a sample, or an operand that is not 16-byte aligned", i,
+                (long long)a_bs[i]);
+    WnFwdParams& q = p.layer[i];
+    q.a = a_in[i]; q.a_bs = a_bs[i]; q.u0 = u0; q.u0_bs = u0_bs; q.img = static_cast<const char*>(images[i]);
+    q.ts = ts[i]; q.acts = nullptr; q.a_next = i == nl - 1 ? nullptr : a_next[i]; q.out = out;
+    q.B = B; q.L = L; q.n = n; q.h = h; q.dil = 1 << i; q.first = i == 0; q.last = i == nl - 1;
+    q.CH = wn_ch(n); q.CH2 = wn_ch2(h); q.tiles_per_seq = L / 256; q.n_wg = 0;
+  }
+  p.nl = nl;
+  // diagnostics: every other workgroup of an XCD starts `stagger` x 3.4 us late (measured: no gain at any value — the phases of a tile
+  // are bound inside the CU, not by the memory system the CUs share; profiles/r04_wn_fwd_stack_timing.txt)
+  static const int stagger_env = getenv("FST_WN_FWD_STAGGER") ? atoi(getenv("FST_WN_FWD_STAGGER")) : -1;
+  p.stagger = stagger_env >= 0 ? stagger_env : 0;
+  const int cus = fst_cu_count() > 0 ? fst_cu_count() : 256;
+  if (int rc = fst_allow_full_lds((const void*)wn_stack_fwd_kernel, "fst_wn_stack_fwd")) return rc;
+  hipLaunchKernelGGL(wn_stack_fwd_kernel, dim3((unsigned)(B < cus ? B : cus)), dim3(512), WN_FWD_LDS(8), (hipStream_t)stream, p);
+  FST_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int fst_wn_layer_fwd(const float* a, int64_t a_bs, const float* u0, int64_t u0_bs, const void* image,
@@ -1225,69 +1404,6 @@ extern "C" int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t im
   return 0;
 }
 
-// Accumulator layout <-> global memory through raw buffer instructions: one descriptor per [rows][L] matrix of a batch element,
-// ONE per-lane byte offset for the whole kernel (vlane = (4·half·L + l31)·4) and the row / column term of every access in the
-// instruction's scalar offset — an access is one buffer_load/store_dword with no VALU work, no 64-bit address and no exec mask
-// (wn_acc_load / _store form sixteen per-lane addresses per tile; the persistent kernel below has no registers for that).
-// Columns beyond the sequence: the lane's offset is pushed out of the descriptor's range (loads return 0, stores are dropped by
-// the hardware's range check).  Rows beyond the matrix: wave-uniform tests per register (the two lane halves of a register
-// are 4 rows apart: a register whose upper half only is out of range goes through the half-masked offset).
-#define WS_OOB 0x80000000u
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x40000000, 0x00020000);
-}
-struct WsLane { unsigned vo, vo_lo; };     // offsets of a lane whose column exists: both halves / lower half only
-__device__ __forceinline__ WsLane ws_lane(unsigned vlane, int tcol, int L, int lane) {
-  WsLane w;
-  w.vo = tcol + (lane & 31) < L ? vlane : WS_OOB;
-  w.vo_lo = lane < 32 ? w.vo : WS_OOB;
-  return w;
-}
-// tile = rows row0 .. row0+31 (rv of them exist, rv may be <= 0 or >= 32), columns tcol .. tcol+31 of the matrix behind `rs`
-// (The scalar offsets are formed from an opaque copy of L: loop-invariant otherwise, the compiler computes those of every tile of
-// the kernel ahead of the layer loop and keeps — i.e. spills — hundreds of them.)
-__device__ __forceinline__ int ws_opaque(int x) {
-  asm volatile("" : "+s"(x));
-  return x;
-}
-template <int AUX = 0>
-__device__ __forceinline__ void ws_acc_load(f32x16& v, __amdgpu_buffer_rsrc_t rs, const WsLane w, int row0, int tcol, int rv, int L) {
-  L = ws_opaque(L);
-  rv = ws_opaque(rv);
-  const int sbase = (row0 * L + tcol) * 4;
-  if (rv >= 32) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, AUX));
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2);
-      float x = 0.f;
-      if (row < rv) x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, AUX));
-      v[r] = x;
-    }
-  }
-}
-template <int AUX = 0, class V>
-__device__ __forceinline__ void ws_acc_store(const V& v, __amdgpu_buffer_rsrc_t rs, const WsLane w, int row0, int tcol, int rv, int L) {
-  L = ws_opaque(L);
-  rv = ws_opaque(rv);
-  const int sbase = (row0 * L + tcol) * 4;
-  if (rv >= 32) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, w.vo, sbase + ((r & 3) + 8 * (r >> 2)) * L * 4, AUX);
-  } else {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2);
-      if (row < rv)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v[r]), rs, row + 4 < rv ? w.vo : w.vo_lo, sbase + row * L * 4, AUX);
-    }
-  }
-}
-
 // Row sums of an accumulator tile WITHOUT an LDS transpose (the persistent kernel's LDS holds a layer's weights): a lane holds
 // 16 rows x 1 column; a halving butterfly over the 32 lanes of a half — at distance 16 a lane keeps registers 0-7 (bit 4 clear)
 // or 8-15 and adds the partner's copy of the same registers, at distance 8 four of those eight, ... — leaves every lane with ONE
@@ -1339,7 +1455,6 @@ __device__ __forceinline__ void ws_row_sums(const float (&v)[16], float* rows_w,
 // wn_layer_dgrad_kernel.  Global stores of one phase (dg, d_u0) are read by the next through LDS-DMA / loads of the SAME
 // workgroup: s_waitcnt vmcnt(0) by every wave + a workgroup barrier orders them (one CU, one L1).
 // ------------------------------------------------------------------------------------------------
-#define WS_MAXL 10
 #ifndef WS_NT
 #define WS_NT 0     // cache policy of the streamed tensors (t,s, dg, d_out): 0 default, 2 non-temporal
 #endif

@@ -1354,6 +1354,40 @@ def wn_stack_bwd_ok(n: int, h: int, L: int, nl: int) -> bool:
     return bool(_lib.load().fst_wn_stack_bwd_ok(n, h, L, nl))
 
 
+def wn_stack_fwd_ok(n: int, h: int, L: int, nl: int, B: int) -> bool:
+    """Whether the forward of a WN stack runs as ONE persistent launch (fst_wn_stack_fwd): sequences that are whole 256-sample
+    tiles, and at least one batch element per CU (fewer would leave CUs without a workgroup where the per-layer launches spread
+    the tiles of a sequence over several)."""
+    if os.environ.get("FST_WN_STACK_FWD", "1") == "0":                            # diagnostics: one launch per layer
+        return False
+    lib = _lib.load()
+    return bool(lib.fst_wn_stack_fwd_ok(n, h, L, nl)) and B * (L // 256) >= 2 * 256 and B >= 256
+
+
+def wn_stack_fwd(a_list: Sequence[Tensor], u0: Tensor, imgs: Sequence[Tensor], ts_list: Sequence[Tensor], out: Tensor, n: int,
+                 h: int) -> None:
+    """All layers of a WN stack's forward in one launch (csrc/wn_fused.hip, fst_wn_stack_fwd): ``a_list[i]`` = input of layer i
+    (``a_list[0]`` = the start conv's output; ``a_list[i + 1]`` is written as layer i's a_next), ``imgs[i]`` = ``wn_pack_layer`` image,
+    ``ts_list[i]`` [B, 2n, L] written, ``out`` [B, n, L] the skip sum."""
+    lib = _lib.load()
+    nl = len(imgs)
+    B, L = u0.size(0), u0.size(2)
+    u0_bs, _ = _ncl(u0, "u0")
+    numel = _same_numel(out, *a_list)
+    bs = (ctypes.c_int64 * nl)(*[_ncl(a, "a")[0] for a in a_list])
+    for ts in ts_list:
+        if ts.numel() != 2 * numel or not ts.is_contiguous():
+            raise ValueError("wn_stack_fwd: every ts must be the contiguous [B, 2n, L] partner of a")
+    t0 = KERNEL_TIMER.begin() if KERNEL_TIMER is not None else None
+    check(lib.fst_wn_stack_fwd(_ptr_table(a_list), bs, _ptr_table(imgs), imgs[0].numel() * 4, _ptr_table(ts_list),
+                               _ptr_table(list(a_list[1:]) + [None]), ptr(u0), u0_bs, ptr(out), nl, B, L, n, h, numel, stream_ptr()),
+          "fst_wn_stack_fwd")
+    if t0 is not None:
+        flops = 2.0 * B * L * (nl * 2 * n * (3 * n + h) + (2 * nl - 1) * n * n)
+        rows = nl * (n + h + 2 * n) + (nl - 1) * (n + 2 * n) + n      # a, u0 in, t,s out; a_next out, out in/out (first layer: out only)
+        KERNEL_TIMER.end("wn_stack_fwd_kernel", t0, flops, 4.0 * B * L * rows)
+
+
 def _ptr_table(ts: Sequence[Optional[Tensor]]):
     arr = (ctypes.c_void_p * len(ts))()
     for i, t in enumerate(ts):
@@ -1419,7 +1453,16 @@ def _wn_forward(specs: WNSpecs, u0: Tensor, flat: Tensor):
         # one launch per layer: dilated conv + cond rows → gate in registers → res_skip → residual / skip adds
         out = torch.empty(B, n, L, device=u0.device, dtype=torch.float32)
         cb = cond_b.view(nl, 2 * n)
-        for i in range(nl):
+        stack = wn_stack_fwd_ok(n, h, L, nl, B)
+        if stack:
+            # ONE launch for all layers (persistent workgroups walk their batch elements through the stack)
+            imgs = [wn_pack_layer(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], in_b[i], cb[i], rs_w[i], rs_b[i], n, h, i == nl - 1)
+                    for i in range(nl)]
+            a_list += [empty_with_slack(B, n, L, u0.device) for _ in range(nl - 1)]
+            ts_list = [torch.empty(B, 2 * n, L, device=u0.device, dtype=torch.float32) for _ in range(nl)]
+            wn_stack_fwd(a_list, u0, imgs, ts_list, out, n, h)
+            a = a_list[-1]
+        for i in range(0 if stack else nl):
             last = i == nl - 1
             img = wn_pack_layer(in_w[i], cond_w[2 * n * i: 2 * n * (i + 1)], in_b[i], cb[i], rs_w[i], rs_b[i], n, h, last)
             ts = torch.empty(B, 2 * n, L, device=u0.device, dtype=torch.float32)

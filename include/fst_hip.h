@@ -263,6 +263,19 @@ int fst_wn_layer_dgrad(const float* dg, const void* image, int64_t image_bytes, 
                        float* row_sums /* optional [128][B·⌈L/512⌉]: per-workgroup Σ_t d_a_new[row] */, int64_t row_sums_rows,
                        int B, int L, int n, int h, int dil, int64_t numel_a, int64_t d_u0_bs, void* stream);
 
+/* The forward of a WHOLE WN stack (every layer of fst_wn_layer_fwd) as ONE persistent launch: one workgroup walks all 256-sample
+ * tiles of its batch elements through all layers — a_next / out of one layer are read by the next through the same CU — so no launch
+ * boundary synchronises the chip and every other workgroup starts half a tile late: one half of the CUs stores while the other
+ * multiplies (the per-layer launches alternate between an idle and a saturated memory system).  Same arithmetic, same results as the
+ * per-layer launches.  Tables of nl entries (host memory, copied into the kernel arguments): a_in[i] = input of layer i with batch
+ * stride a_bs[i] (a_in[0] = the start conv's output, a_in[i+1] = a_next[i]), images[i] = fst_wn_pack image, ts[i] [B][2n][L] written,
+ * a_next[i] [B][n][L] written (NULL on the last layer); out [B][n][L] the skip sum (written).  fst_wn_stack_fwd_ok: n < 128,
+ * L % 256 == 0, nl <= 10.  Replaces the layer loop of WN.forward, /root/reference/Simplified_NF_WaveGlow.py:101-123. */
+int fst_wn_stack_fwd_ok(int n, int h, int L, int nl);
+int fst_wn_stack_fwd(const float* const* a_in, const int64_t* a_bs, const void* const* images, int64_t image_bytes, float* const* ts,
+                     float* const* a_next, const float* u0, int64_t u0_bs, float* out, int nl, int B, int L, int n, int h,
+                     int64_t numel_a, void* stream);
+
 /* The whole backward of a WN stack — fst_wn_layer_bwd and fst_wn_layer_dgrad of every layer, top layer first — as ONE persistent
  * launch (the backward autograd derives for the loop of Simplified_NF_WaveGlow.py:104-121), for sequences of up to 512 samples:
  * a 512-sample tile is then a whole sequence, the dilated taps never leave it, and one workgroup walks all layers of its batch

@@ -371,3 +371,49 @@ def test_wn_stack_backward_in_one_launch(n, h, Bq, L, nl, monkeypatch):
     with ops.pack_cache():
         d_u0, d_fl = torch.autograd.grad(ops.WNFn.apply(S, u0, fl), (u0, fl), do)
     assert torch.equal(d_u0, runs[("1", False)][1]) and torch.equal(d_fl, runs[("1", False)][2])
+
+
+@bf3_only
+@pytest.mark.parametrize("n,h,Bq,L,nl", [(120, 25, 256, 512, 8),     # the metric configuration: one sequence per CU
+                                         (120, 25, 600, 256, 8),     # more sequences than CUs (persistent loop), one tile per sequence
+                                         (120, 25, 256, 1024, 8),    # configs[4]'s length: four tiles per sequence, every dilation inside a tile row
+                                         (16, 5, 512, 256, 3)])      # few rows, three layers
+def test_wn_stack_forward_in_one_launch(n, h, Bq, L, nl, monkeypatch):
+    """fst_wn_stack_fwd — every layer's forward of a WN stack as one persistent launch (every other workgroup starting half a
+    tile late) — against the per-layer launches it replaces: the same tile body on the same operands, so the SAME BITS (output,
+    every saved gate half, and through them every gradient), and against the fp64 reference of Simplified_NF_WaveGlow.py:101-123."""
+    g = torch.Generator(device=DEV).manual_seed(n * 17 + L + nl)
+    S = ops.WNSpecs(h, n, nl)
+    ws = []
+    for j, sh in enumerate(S.shapes):
+        fan = sh[1] * sh[2] if len(sh) == 3 else 1
+        ws.append(_rnd(g, *sh, k=(1.0 / fan ** 0.5 if len(sh) == 3 else 0.1)))
+    flat = S.flatten(ws)
+    x = _rnd(g, Bq, 2 * h, L)
+    do = _rnd(g, Bq, 2 * h, L)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FST_WN_STACK_FWD", mode)
+        assert ops.wn_stack_fwd_ok(n, h, L, nl, Bq) == (mode == "1")
+        u0 = x[:, :h].detach().requires_grad_(True)
+        fl = flat.detach().clone().requires_grad_(True)
+        timer = ops.KernelTimer()
+        ops.KERNEL_TIMER = timer
+        try:
+            with ops.pack_cache():
+                o = ops.WNFn.apply(S, u0, fl)
+        finally:
+            ops.KERNEL_TIMER = None
+        keys = timer.summary()
+        assert ("wn_stack_fwd_kernel" in keys) == (mode == "1") and ("wn_layer_fwd_kernel" in keys) == (mode == "0"), sorted(keys)
+        with ops.pack_cache():
+            d_u0, d_fl = torch.autograd.grad(o, (u0, fl), do)
+        runs[mode] = (o.detach(), d_u0, d_fl)
+    for a, b, what in zip(runs["1"][:2], runs["0"][:2], ("output", "d_u0")):
+        assert torch.equal(a, b), f"one-launch forward vs per-layer launches: {what} differs"
+    # (weight gradients: the same operands in both runs; shapes the time-as-k kernels do not serve sum with fp32 atomics)
+    assert_close(runs["1"][2], runs["0"][2], 1e-6, "weight gradients behind the one-launch forward vs behind the per-layer launches")
+    if Bq * L <= 256 * 512:
+        o_ref, du_ref, _ = _wn_reference_f64(S, x[:, :h], flat, do)
+        assert_close(runs["1"][0], o_ref, 2e-5, "WN output vs fp64")
+        assert_close(runs["1"][1], du_ref, 5e-5, "d_u0 vs fp64")
