@@ -421,15 +421,20 @@ __global__ __launch_bounds__(512, 2) void wn_wgrad_kernel(WwParams p) {
       issue_pos(5 * ks);
 #pragma unroll
       for (int j = 0; j < KT; ++j) {
-        if (!FULL && wk * KT + j >= k_blocks_here) break;  // wave-uniform: blocks beyond K hold zeros
-        const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[j][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[j][1]);
+        // (blocks beyond K hold zeros: their products are skipped — wave-uniform — but NOT the LDS-DMA piece issued behind them:
+        // a `break` here once left the later stages of a workgroup without part of their operands whenever a wave had a dead
+        // k-row block, i.e. for every n <= 96 once a workgroup had more than one stage; found by the many-tile small-n cases of
+        // test_time_as_k_weight_gradient_kernels)
+        if (FULL || wk * KT + j < k_blocks_here) {
+          const ww_bf16x8 bh = __builtin_bit_cast(ww_bf16x8, braw[j][0]), bl = __builtin_bit_cast(ww_bf16x8, braw[j][1]);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          if (!FULL && wm * MT + i >= m_blocks) break;     // wave-uniform
-          const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[i][1]);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+          for (int i = 0; i < MT; ++i) {
+            if (!FULL && wm * MT + i >= m_blocks) break;   // wave-uniform
+            const ww_bf16x8 ah = __builtin_bit_cast(ww_bf16x8, araw[i][0]), al = __builtin_bit_cast(ww_bf16x8, araw[i][1]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+          }
         }
         issue_pos(5 * ks + 1 + j);
       }

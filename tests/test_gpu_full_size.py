@@ -220,7 +220,8 @@ def test_joint_step_gradients_at_batch_32(arithmetic):
 @pytest.mark.parametrize("n,h,Bq,L,dil", [(120, 25, 256, 512, 4), (120, 25, 256, 512, 128), (120, 25, 64, 1024, 16),
                                           (120, 25, 256, 512, 1), (120, 25, 256, 512, 2), (33, 31, 3, 64, 1), (8, 3, 2, 32, 2), (16, 5, 2, 64, 3),
                                           (8, 3, 3, 64, 4), (33, 31, 2, 96, 8), (127, 32, 2, 128, 4), (16, 16, 5, 32, 8),
-                                          (120, 25, 1, 32, 4)])      # one tile in all: most workgroups have nothing to do
+                                          (120, 25, 1, 32, 4),       # one tile in all: most workgroups have nothing to do
+                                          (16, 5, 512, 256, 4), (48, 5, 64, 256, 2)])   # few rows, many tiles: every workgroup of the K split busy
 def test_time_as_k_weight_gradient_kernels(n, h, Bq, L, dil):
     """csrc/wn_wgrad.hip (time as the MFMA reduction index, per-workgroup slabs added in a fixed order) against fp64 einsums:
     in_layer + cond_layer (three dilated taps, the 385th k-row on the VALU) and res_skip with acts = t·s re-formed from the saved
@@ -400,14 +401,13 @@ def test_wn_stack_forward_in_one_launch(n, h, Bq, L, nl, monkeypatch):
         timer = ops.KernelTimer()
         ops.KERNEL_TIMER = timer
         try:
-            with ops.pack_cache():
+            with ops.pack_cache():                                      # (one scope around forward and backward, as the train step has)
                 o = ops.WNFn.apply(S, u0, fl)
+                d_u0, d_fl = torch.autograd.grad(o, (u0, fl), do)
         finally:
             ops.KERNEL_TIMER = None
         keys = timer.summary()
         assert ("wn_stack_fwd_kernel" in keys) == (mode == "1") and ("wn_layer_fwd_kernel" in keys) == (mode == "0"), sorted(keys)
-        with ops.pack_cache():
-            d_u0, d_fl = torch.autograd.grad(o, (u0, fl), do)
         runs[mode] = (o.detach(), d_u0, d_fl)
     for a, b, what in zip(runs["1"][:2], runs["0"][:2], ("output", "d_u0")):
         assert torch.equal(a, b), f"one-launch forward vs per-layer launches: {what} differs"
