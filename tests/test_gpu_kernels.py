@@ -650,7 +650,8 @@ def test_noise_transfer_kernels_vs_fp64_composition(B, C, L, device_ratios):
 
 
 @bf3_only
-@pytest.mark.parametrize("M,N,K", [(256, 1024, 25600), (256, 25600, 1024), (3, 5, 32), (200, 130, 96), (33, 129, 64), (1, 1, 32)])
+@pytest.mark.parametrize("M,N,K", [(256, 1024, 25600), (256, 25600, 1024), (3, 5, 32), (200, 130, 96), (33, 129, 64), (1, 1, 32),
+                                   (100, 200, 8192), (37, 70, 4096)])      # dead row / k-row blocks AND several stages per workgroup
 def test_nt_gemm_vs_fp64(M, N, K):
     """fst_nt_gemm (C = A·Bmᵀ on the time-as-k kernel, K split into slabs added in a fixed order) against fp64; bit-identical twice."""
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
