@@ -829,13 +829,6 @@ struct TzParams {
   int m_halves;                 // 1, or 2: workgroup z takes the rows [128·z, min(M, 128·z + 128))
 };
 
-__device__ __forceinline__ float tz_lds_read4(const char* p) {
-  float v;
-  const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
-  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
-}
-
 template <int N>
 __device__ __forceinline__ void tz_wait_at_most() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

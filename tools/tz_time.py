@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostics: HIP-event time of the dense many-tap weight gradient (fst_dense_tap_wgrad) at the bench's three shapes.
-FST_TZ_EXP=<mask> removes one cost at a time (timing only): 1 no MFMAs, 2 no split pass, 4 no LDS-DMA."""
+Cost removal: build a diagnostic library with tools/build_tz_exp.sh <mask> (1 no MFMAs, 2 no split pass, 4 no LDS-DMA, 8 no fragment
+reads, 16 no slab stores, 32 no stages) and run with FST_HIP_LIB=build/exp/libfst_tzexp<mask>.so (the first column names the library)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,7 @@ from feature_level_style_transfer_for_tsc_amd import ops
 
 dev = "cuda"
 B, L = 256, 512
-out = [f"FST_TZ_EXP={os.environ.get('FST_TZ_EXP', '0')}"]
+out = [os.path.basename(os.environ.get("FST_HIP_LIB", "libfst_hip.so"))]
 for (M, C, K) in ((225, 25, 89), (25, 50, 89), (25, 1, 89)):
     x, dy, dw = torch.randn(B, C, L, device=dev), torch.randn(B, M, L, device=dev), torch.empty(M, C, K, device=dev)
     fn = lambda: ops.dense_tap_wgrad(dy, x, dw, M, C, K, (K - 1) // 2)
