@@ -64,7 +64,10 @@ class CPC(nn.Module):
         if self.hidden_dim == 64 and features.is_cuda:
             # the input projections of all S steps as one GEMM, then the recurrence as ONE persistent launch
             # (ops.GRULastFn) — nn.GRU's parameters are used as they are (torch's r | z | n gate order)
-            xproj = torch.matmul(z[:, :S, :], self.gru.weight_ih_l0.t()) + self.gru.bias_ih_l0
+            if ops.MATH == "bf16x3":
+                xproj = ops.LinearActFn.apply(z[:, :S, :], self.gru.weight_ih_l0, self.gru.bias_ih_l0, ops.ACT_NONE, 0.0)
+            else:
+                xproj = torch.matmul(z[:, :S, :], self.gru.weight_ih_l0.t()) + self.gru.bias_ih_l0
             c_t = ops.GRULastFn.apply(xproj, self.gru.weight_hh_l0, self.gru.bias_hh_l0, t_samples)
         elif dev_t:
             output, _ = self.gru(z[:, :S, :].contiguous())

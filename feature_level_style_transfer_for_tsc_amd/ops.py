@@ -2026,7 +2026,13 @@ class GRULastFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             # dW_hh = Σ_{b,s} dgh[b,s] ⊗ h[b,s−1]  (h_{−1} = 0; steps beyond t_last carry zeros in dgh)
             g2 = dgh[:, 1:, :].reshape(-1, 3 * H)
-            d_w = g2.t() @ h_all[:, :-1, :].reshape(-1, H) if S > 1 else torch.zeros_like(w_hh)
+            if S > 1:
+                hp = h_all[:, :-1, :].reshape(-1, H)
+                # a [3H, H] product with a reduction of B·(S−1) ≈ 2·10⁴: the K split of fst_gemm fills the chip (the library
+                # picks 6 workgroups for it: 130 µs)
+                d_w = gemm(g2, True, hp, True) if gemm_ok(g2, hp) else g2.t() @ hp
+            else:
+                d_w = torch.zeros_like(w_hh)
             d_b = dgh.sum(dim=(0, 1))
         return dxproj, d_w, d_b, None
 
