@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -64,7 +66,7 @@ class CPC(nn.Module):
         if self.hidden_dim == 64 and features.is_cuda:
             # the input projections of all S steps as one GEMM, then the recurrence as ONE persistent launch
             # (ops.GRULastFn) — nn.GRU's parameters are used as they are (torch's r | z | n gate order)
-            if ops.MATH == "bf16x3":
+            if ops.MATH == "bf16x3" and os.environ.get("FST_CPC_GEMM", "1") != "0":      # (0: diagnostics, the library GEMM)
                 xproj = ops.LinearActFn.apply(z[:, :S, :], self.gru.weight_ih_l0, self.gru.bias_ih_l0, ops.ACT_NONE, 0.0)
             else:
                 xproj = torch.matmul(z[:, :S, :], self.gru.weight_ih_l0.t()) + self.gru.bias_ih_l0

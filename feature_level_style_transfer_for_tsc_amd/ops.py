@@ -2030,7 +2030,7 @@ class GRULastFn(torch.autograd.Function):
                 hp = h_all[:, :-1, :].reshape(-1, H)
                 # a [3H, H] product with a reduction of B·(S−1) ≈ 2·10⁴: the K split of fst_gemm fills the chip (the library
                 # picks 6 workgroups for it: 130 µs)
-                d_w = gemm(g2, True, hp, True) if gemm_ok(g2, hp) else g2.t() @ hp
+                d_w = gemm(g2, True, hp, True) if gemm_ok(g2, hp) and os.environ.get("FST_CPC_GEMM", "1") != "0" else g2.t() @ hp
             else:
                 d_w = torch.zeros_like(w_hh)
             d_b = dgh.sum(dim=(0, 1))
