@@ -65,3 +65,34 @@ def test_product_code_never_touches_the_oracle():
         assert not oracle_imports(path), f"{path} imports the oracle"
     assert oracle_imports(os.path.join(root, "bench.py")) == {"cpu_baseline"}
     assert oracle_imports(os.path.join(root, "__graft_entry__.py")) == {"smoke"}
+
+
+def test_row_sum_handover_is_tied_to_the_tensor_it_was_computed_from():
+    """ops._RowSums (BatchNorm backward → the bias gradient of the conv in front): the sums ride on the cotangent tensor object and
+    are handed out only while that tensor is what they were computed from — same object, same version counter, same shape."""
+    dx = torch.randn(4, 5, 32)
+    rs = dx.sum(dim=2)
+    assert ops._ROW_SUMS.take(dx) is None
+    ops._ROW_SUMS.attach(dx, rs)
+    assert ops._ROW_SUMS.take(dx) is rs
+    assert ops._ROW_SUMS.take(dx.clone()) is None                 # another tensor
+    assert ops._ROW_SUMS.take(dx.transpose(1, 2)) is None         # a view with other strides
+    dx.add_(1.0)                                                  # rewritten in place (e.g. autograd accumulating into it)
+    assert ops._ROW_SUMS.take(dx) is None
+    ops._ROW_SUMS.attach(dx, torch.zeros(4, 6))                   # sums of another shape
+    assert ops._ROW_SUMS.take(dx) is None
+
+
+def test_dense_products_refuse_what_the_kernel_does_not_serve():
+    """ops.gemm / LinearActFn run on the GPU library only: CPU tensors, other dtypes and mismatched reduction lengths are refused
+    before anything is launched; ops.linear_act falls back to the framework's Linear only outside the GPU split-bf16 mode."""
+    a, b = torch.zeros(4, 8), torch.zeros(3, 8)
+    assert not ops.gemm_ok(a, b)
+    with pytest.raises(ValueError):
+        ops.gemm(a, False, b, False)
+    lin = torch.nn.Linear(8, 3)
+    x = torch.randn(5, 8)
+    want = torch.nn.functional.leaky_relu(lin(x), 0.2)
+    assert torch.equal(ops.linear_act(x, lin, ops.ACT_LEAKY, 0.2), want)          # CPU tensors: the framework's composition
+    assert torch.equal(ops.linear_act(x, lin, ops.ACT_RELU), torch.relu(lin(x)))
+    assert torch.equal(ops.linear_act(x, lin), lin(x))
