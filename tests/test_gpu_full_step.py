@@ -304,7 +304,13 @@ def test_full_batch_graph_replay_equals_eager_step():
     tr.restore(snap)
     rep2 = tr.replay(*args, (31, 77))
     for k, v in rep.items():
-        assert torch.equal(rep2[k], v), f"two replays differ in {k}: {float((rep2[k].double() - v.double()).abs().max()):.3e}"
+        diff = float((rep2[k].double() - v.double()).abs().max())
+        if _ops.MATH == "bf16x3":
+            assert torch.equal(rep2[k], v), f"two replays differ in {k}: {diff:.3e}"
+        else:
+            # FST_MATH=f32: RandomLayer's products run on the conv engine's K-split GEMM with float atomics (see below): the CDAN
+            # branch — forward value included — moves in the last bits from run to run
+            assert diff <= 1e-5 * max(1.0, float(v.double().abs().max())), f"two replays differ in {k}: {diff:.3e}"
     again = tr.snapshot()["t"]
     differing = [k for k, v in after_graph["t"].items() if not torch.equal(again[k], v)]
     # FST_MATH=f32: fst_nt_gemm is a split-bf16 kernel, so RandomLayer's 25600 x 1024 products fall back to the conv engine's K-split
